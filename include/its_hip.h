@@ -1,0 +1,130 @@
+/* its_hip.h — C ABI of libits_hip.so: the gfx950 (MI355X) implementation of the
+ * DanecLacey/iterative_solvers solver hot path.
+ *
+ * The reference has no FFI: its seam is the set of Solver<VT> methods that preprocessing()
+ * and solve_cpu() call with raw pointers.  Each entry point below names the
+ * reference call site it replaces (paths relative to the reference root).  All functions
+ * return 0 on success or a negative ITS_E* code; nothing throws, nothing calls exit().
+ * Threading: one caller thread per handle; a handle is bound to the HIP device that was
+ * current when it was created.  Host buffers stay owned by the caller, device memory by the
+ * handle.  All values are fp64, all indices int32 (sparse_matrix.hpp:20-27).
+ */
+#ifndef ITS_HIP_H
+#define ITS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct its_handle its_handle;
+
+enum { ITS_OK = 0, ITS_EINVAL = -1, ITS_EHIP = -2, ITS_ESTATE = -3, ITS_ENOMEM = -4,
+       ITS_ECOMM = -5, ITS_EUNSUPPORTED = -6 };
+
+/* solver kinds = the strings Solver<VT> dispatches on (solver.hpp:411,441,467,509) */
+enum { ITS_JACOBI = 0, ITS_GAUSS_SEIDEL = 1, ITS_CG = 2, ITS_GMRES = 3 };
+/* Jacobi flavour: SHIPPED reproduces methods/jacobi.hpp:191 (SpMV arguments swapped),
+ * REF is jacobi_iteration_ref_cpu (methods/jacobi.hpp:65-93), the correct sweep. */
+enum { ITS_JACOBI_SHIPPED = 0, ITS_JACOBI_REF = 1 };
+enum { ITS_PRECOND_NONE = 0, ITS_PRECOND_JACOBI = 1, ITS_PRECOND_GS = 2 };
+/* SpMV formats (sparse_matrix.hpp:11-64 is the CRS layout; SELL-C-sigma layout follows
+ * CUDA_tests/helpers/utilities.cpp:183-361 with C = 64).
+ *   ITS_FMT_CSR_EXACT : one lane per row, in-order fused multiply-add from 0 — bit-identical
+ *                       to spmv_crs_cpu (kernels.hpp:380-409); col/val streamed through LDS.
+ *   ITS_FMT_CSR_VECTOR: 2^k lanes per row chosen from the row-length histogram; 1e-12 rel.
+ *   ITS_FMT_SELL      : SELL-64-sigma; 1e-12 rel.                                         */
+enum { ITS_FMT_CSR_EXACT = 0, ITS_FMT_CSR_VECTOR = 1, ITS_FMT_SELL = 2 };
+/* which matrix of SparseMtxFormat<VT> (sparse_matrix.hpp:352-394) an upload fills */
+enum { ITS_MAT_A = 0, ITS_MAT_L = 1, ITS_MAT_U = 2 };
+/* Gauss-Seidel sweep order.  NATURAL = the reference's serial forward substitution order
+ * (kernels.hpp:451-473) executed level by level (rows of one dependency level in parallel:
+ * identical arithmetic per row, hence identical iterates); MULTICOLOR = greedy colouring,
+ * rows of one colour in parallel (a different splitting unless the caller pre-permutes). */
+enum { ITS_GS_LEVEL = 0, ITS_GS_MULTICOLOR = 1 };
+
+/* ---- library / handle --------------------------------------------------------------- */
+/* start of run_solver (main.cpp:331).  device < 0 keeps the current device. */
+int its_create(its_handle **h, int device);
+/* end of run_solver (main.cpp:492-519) */
+int its_destroy(its_handle *h);
+const char *its_last_error(const its_handle *h);
+const char *its_version(void);
+
+/* ---- matrix / vectors --------------------------------------------------------------- */
+/* after convert_to_crs (main.cpp:221-229); again for crs_L / crs_U
+ * (methods/gauss_seidel.hpp:433-450).  Builds the row-block plan / SELL image on the host. */
+int its_upload_crs(its_handle *h, int which, int n_rows, int n_cols, int64_t nnz,
+                   const int *row_ptr, const int *col, const double *val, int format);
+/* after extract_diag + generate_vector + scale_vector (main.cpp:268-276): D, b, x_old. */
+int its_upload_vectors(its_handle *h, const double *D, const double *b, const double *x0, int n);
+/* Solver::init_residual (solver.hpp:838-855) + both norms that
+ * LoopParams::compute_stopping_criteria (structs.hpp:41-68) chooses between. */
+int its_init_residual(its_handle *h, double *r0_inf, double *r0_two);
+/* allocate_*_structs + Solver::init_structs (solver.hpp:335-378, 381-401). */
+int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precond_kind,
+                     int jacobi_mode, int gs_order);
+
+/* ---- the loop body (solver_harness.hpp:40-116) -------------------------------------- */
+/* Solver::iterate + record_residual_norm's value + Solver::exchange_arrays
+ * (solver_harness.hpp:43-90).  Blocks until the scalar is on the host.  *residual_norm is what
+ * the reference records: ||r||_2 (Jacobi/GS: of b - A x after the sweep; CG: of the
+ * recurrence residual) or |g[k+1]| (GMRES, methods/gmres.hpp:658). */
+int its_iterate(its_handle *h, int iter_count, double *residual_norm);
+/* n_trips iterations back to back with ONE host sync at the end; residuals[n_trips] receives
+ * every trip's value.  Same arithmetic as n_trips its_iterate calls (bench / fixed-count use). */
+int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double *residuals);
+/* Solver::restart_gmres (solver_harness.hpp:98-104, solver.hpp:552-656) */
+int its_gmres_restart(its_handle *h, int iter_count);
+/* Solver::save_x_star (solver_harness.hpp:120, solver.hpp:658-726); iter_count as passed by
+ * the harness (GMRES back-substitutes with iter_count - 1). */
+int its_download_x(its_handle *h, double *x_star, int n, int iter_count);
+/* post-loop record_residual_norm (solver_harness.hpp:122-149): Jacobi/GS recompute
+ * ||b - A x_star||_2, CG returns the norm of Solver::r after the swaps, GMRES the last value */
+int its_final_residual(its_handle *h, double *residual_norm);
+
+/* ---- kernels alone (bench + parity tests; kernels.hpp) ------------------------------ */
+/* where: 0 = x,y are host pointers (copied), 1 = device pointers.  kernels.hpp:380-409 */
+int its_spmv(its_handle *h, int which, const double *x, double *y, int where, int format);
+/* Device-pointer BLAS-1 with deterministic fixed-order reductions.  Result to *out (host). */
+int its_dot(its_handle *h, const double *a_dev, const double *b_dev, int64_t n, double *out);      /* kernels.hpp:170-183 */
+int its_nrm2(its_handle *h, const double *v_dev, int64_t n, double *out);                          /* kernels.hpp:542-556 */
+int its_norm_inf(its_handle *h, const double *v_dev, int64_t n, double *out);                      /* kernels.hpp:558-575 */
+int its_axpby(its_handle *h, double *out_dev, const double *a_dev, const double *b_dev,
+              int64_t n, double s);          /* out = a + s*b: sum_vectors_cpu / subtract (s<0) kernels.hpp:54-87 */
+int its_scale(its_handle *h, double *out_dev, const double *v_dev, double s, int64_t n);           /* kernels.hpp:136-168 */
+/* forward solve (D+L) x = rhs, device pointers; kernels.hpp:451-473 (needs ITS_MAT_L + D) */
+int its_spltsv(its_handle *h, double *x_dev, const double *rhs_dev);
+
+/* plain device memory helpers for callers without a HIP runtime of their own */
+int its_dev_alloc(its_handle *h, void **p, size_t bytes);
+int its_dev_free(its_handle *h, void *p);
+int its_memcpy_h2d(its_handle *h, void *dst_dev, const void *src, size_t bytes);
+int its_memcpy_d2h(its_handle *h, void *dst, const void *src_dev, size_t bytes);
+int its_synchronize(its_handle *h);
+
+/* ---- introspection for bench.py ----------------------------------------------------- */
+/* average duration (ms) of the last its_spmv_timed / its_iterate_n region, measured with HIP
+ * events on the handle's own stream */
+int its_spmv_timed(its_handle *h, int which, const double *x_dev, double *y_dev, int format,
+                   int reps, float *avg_ms);
+int its_last_region_ms(its_handle *h, float *ms);
+/* plan facts: lanes per row chosen, SELL occupancy (nnz / stored elements), row-block count */
+int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occupancy,
+                  int *n_row_blocks);
+
+/* ---- multi-GPU (no counterpart in the reference, which is single-process) -- */
+/* One process per GPU.  The caller (bench.py, via torch.distributed/gloo) obtains the 128-byte
+ * RCCL unique id from rank 0 with its_comm_unique_id and hands it to every rank. */
+int its_comm_unique_id(void *id128);
+int its_comm_init(its_handle *h, int rank, int world, const void *id128);
+/* Row-block partition of a GLOBAL n_global-row matrix: this rank owns rows
+ * [row_begin, row_begin + n_rows); col[] holds GLOBAL column indices.  The library renumbers
+ * columns to owned + halo, builds send/recv lists and splits interior/boundary rows. */
+int its_upload_crs_dist(its_handle *h, int64_t n_global, int64_t row_begin, int n_rows, int64_t nnz,
+                        const int *row_ptr, const int64_t *col_global, const double *val, int format);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ITS_HIP_H */

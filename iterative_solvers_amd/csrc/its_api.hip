@@ -1,0 +1,863 @@
+// its_api.hip — the extern "C" boundary of libits_hip.so (declared in include/its_hip.h).
+// Host-side state machine that mirrors Solver<VT> (reference solver.hpp) with every vector
+// resident in HBM; the only per-trip host traffic is one 8-byte scalar (GMRES: one H column).
+#include "../../include/its_hip.h"
+#include "its_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace its;
+
+// ---------------------------------------------------------------------------------------
+struct DistPlan;   // its_dist.hip (multi-GPU); opaque here
+
+struct its_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_region_ms = 0.f;
+    std::string err;
+
+    CsrDev mat[3];
+    bool have[3] = {false, false, false};
+    int fmt = ITS_FMT_CSR_EXACT;          // format used by the solver loops for A
+
+    int n = 0;                            // owned rows
+    int n_ext = 0;                        // owned + halo (== n on one GPU)
+    // Solver<VT> vectors (solver.hpp:23-34).  x_a/x_b ping-pong as x_old/x_new.
+    double *D = nullptr, *b = nullptr, *r = nullptr, *tmp = nullptr;
+    double *x_a = nullptr, *x_b = nullptr, *x = nullptr;   // x: GS / GMRES iterate
+    // cgArgs (cg.hpp:16-38): p and q=A p; r is shared
+    double *p = nullptr;
+    // gmresArgs (gmres.hpp:16-42)
+    double *V = nullptr, *hcol_dev = nullptr, *y_dev = nullptr;
+    int m = 0, restart_count = 0;
+    double beta = 0.0;
+    std::vector<double> Rm, g, cs, sn, hcol;   // host: R (col-major (m+1) x m), g, Givens c/s
+    // reductions / scalars
+    double *part[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *sc = nullptr;                 // SC_COUNT device scalars
+    double *res_dev = nullptr;            // per-trip residuals for its_iterate_n
+    int res_cap = 0;
+    double *pinned = nullptr;             // small pinned host buffer
+    int rr_slot = 0;
+
+    int solver = -1, precond = 0, jacobi_mode = 0, gs_order = 0;
+    bool setup_done = false, residual_done = false;
+    double last_residual = 0.0;
+    // triangular sweep schedule (levels of L; colours when the matrix was colour-permuted)
+    std::vector<int> level_ptr;           // host offsets into level_rows
+    int *level_rows = nullptr;            // device
+    int n_levels = 0;
+    // multicolour permutation (gs_order == ITS_GS_MULTICOLOR): new index -> old index
+    std::vector<int> mc_perm, mc_iperm;
+
+    DistPlan *dist = nullptr;
+};
+
+#define HIPCHK(h, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return ITS_EHIP;                                                                \
+        }                                                                                   \
+    } while (0)
+#define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
+
+template <class T> static int dalloc(its_handle *h, T **p, size_t count)
+{
+    void *q = nullptr;
+    HIPCHK(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T) + 256));
+    *p = (T *)q;
+    return ITS_OK;
+}
+template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+static void free_csr(CsrDev &A)
+{
+    dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_row);
+    dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val);
+    A = CsrDev();
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" const char *its_version(void) { return "its_hip 0.1 (gfx950)"; }
+extern "C" const char *its_last_error(const its_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int its_create(its_handle **out, int device)
+{
+    if (!out) return ITS_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ITS_EHIP;
+    its_handle *h = new its_handle;
+    if (device >= 0) { if (hipSetDevice(device) != hipSuccess) { delete h; return ITS_EHIP; } }
+    (void)hipGetDevice(&h->device);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ITS_EHIP; }
+    (void)hipEventCreate(&h->ev0); (void)hipEventCreate(&h->ev1);
+    for (int i = 0; i < 4; ++i) {
+        if (dalloc(h, &h->part[i], ITS_NPART) != ITS_OK) { delete h; return ITS_EHIP; }
+        (void)hipMemsetAsync(h->part[i], 0, ITS_NPART * sizeof(double), h->stream);
+    }
+    if (dalloc(h, &h->sc, SC_COUNT) != ITS_OK) { delete h; return ITS_EHIP; }
+    (void)hipMemsetAsync(h->sc, 0, SC_COUNT * sizeof(double), h->stream);
+    if (hipHostMalloc((void **)&h->pinned, 4096 * sizeof(double), hipHostMallocDefault) != hipSuccess) { delete h; return ITS_EHIP; }
+    (void)hipStreamSynchronize(h->stream);
+    *out = h;
+    return ITS_OK;
+}
+
+void its_dist_destroy(its_handle *h);   // its_dist.hip
+
+extern "C" int its_destroy(its_handle *h)
+{
+    if (!h) return ITS_EINVAL;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    its_dist_destroy(h);
+    for (auto &A : h->mat) free_csr(A);
+    dfree(h->D); dfree(h->b); dfree(h->r); dfree(h->tmp); dfree(h->x_a); dfree(h->x_b); dfree(h->x);
+    dfree(h->p); dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
+    for (auto &p : h->part) dfree(p);
+    dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows);
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return ITS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side plans
+// ---------------------------------------------------------------------------------------
+static void build_stream_plan(int n, const int *rp, std::vector<int> &blk)
+{
+    blk.clear(); blk.push_back(0);
+    int rs = 0;
+    while (rs < n) {
+        int re = rs + 1;                                     // a block always takes one row
+        const int64_t a0 = rp[rs];
+        while (re < n && re - rs < ITS_BLOCK && (int64_t)rp[re + 1] - a0 <= SPMV_NNZ_MAX) ++re;
+        blk.push_back(re);
+        rs = re;
+    }
+}
+
+static int pick_lanes_per_row(int n, int64_t nnz)
+{
+    const double mean = n > 0 ? (double)nnz / n : 1.0;
+    int l = 2;
+    while (l < 64 && l < mean) l <<= 1;                      // 7-pt -> 8, 27-pt -> 32
+    return l;
+}
+
+// SELL-64-sigma image, layout of CUDA_tests/helpers/utilities.cpp:183-361 (C = 64): rows sorted
+// by descending length inside windows of sigma rows, chunk c stored column-major at
+// chunk_ptr[c] + j*64 + r, padding = (col 0, val 0.0).
+static int build_sell(its_handle *h, CsrDev &A, int n, const int *rp, const int *col, const double *val)
+{
+    const int C = 64;
+    int sigma = 4096;
+    if (const char *e = getenv("ITS_SELL_SIGMA")) sigma = std::max(1, atoi(e));
+    const int n_chunks = (n + C - 1) / C, n_pad = n_chunks * C;
+    std::vector<int> order(n_pad);
+    std::iota(order.begin(), order.end(), 0);
+    auto len = [&](int r) { return r < n ? rp[r + 1] - rp[r] : 0; };
+    if (sigma > 1)
+        for (int i = 0; i < n_pad; i += sigma)
+            std::stable_sort(order.begin() + i, order.begin() + std::min(n_pad, i + sigma),
+                             [&](int a, int b) { return len(a) > len(b); });
+    std::vector<int> cptr(n_chunks + 1), clen(n_chunks), perm(n_pad);
+    int64_t tot = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        int mx = 0;
+        for (int r = 0; r < C; ++r) mx = std::max(mx, len(order[c * C + r]));
+        clen[c] = mx;
+        if (tot > INT32_MAX) FAIL(h, ITS_EUNSUPPORTED, "SELL image exceeds int32 offsets");
+        cptr[c] = (int)tot;
+        tot += (int64_t)mx * C;
+    }
+    if (tot > INT32_MAX) FAIL(h, ITS_EUNSUPPORTED, "SELL image exceeds int32 offsets");
+    cptr[n_chunks] = (int)tot;
+    std::vector<int> scol((size_t)tot, 0);
+    std::vector<double> sval((size_t)tot, 0.0);
+    for (int c = 0; c < n_chunks; ++c)
+        for (int r = 0; r < C; ++r) {
+            const int row = order[c * C + r];
+            perm[c * C + r] = row < n ? row : -1;
+            if (row >= n) continue;
+            for (int j = rp[row]; j < rp[row + 1]; ++j) {
+                const size_t idx = (size_t)cptr[c] + (size_t)(j - rp[row]) * C + r;
+                scol[idx] = col[j]; sval[idx] = val[j];
+            }
+        }
+    A.sell_chunks = n_chunks; A.sell_sigma = sigma; A.sell_elems = tot;
+    if (dalloc(h, &A.sell_chunk_ptr, n_chunks + 1) || dalloc(h, &A.sell_chunk_len, n_chunks) ||
+        dalloc(h, &A.sell_perm, n_pad) || dalloc(h, &A.sell_col, (size_t)tot) || dalloc(h, &A.sell_val, (size_t)tot))
+        return ITS_EHIP;
+    HIPCHK(h, hipMemcpy(A.sell_chunk_ptr, cptr.data(), (n_chunks + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(A.sell_chunk_len, clen.data(), n_chunks * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(A.sell_perm, perm.data(), n_pad * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(A.sell_col, scol.data(), (size_t)tot * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(A.sell_val, sval.data(), (size_t)tot * sizeof(double), hipMemcpyHostToDevice));
+    return ITS_OK;
+}
+
+int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64_t nnz,
+                         const int *row_ptr, const int *col, const double *val, int format)
+{
+    if (!h || which < 0 || which > 2 || n_rows < 0 || nnz < 0 || !row_ptr) return ITS_EINVAL;
+    if (nnz > 0 && (!col || !val)) FAIL(h, ITS_EINVAL, "null col/val");
+    if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) FAIL(h, ITS_EINVAL, "row_ptr[0] != 0 or row_ptr[n] != nnz");
+    if (nnz > INT32_MAX - 16) FAIL(h, ITS_EUNSUPPORTED, "nnz exceeds int32 offsets (sparse_matrix.hpp:20-27)");
+    HIPCHK(h, hipSetDevice(h->device));
+    CsrDev &A = h->mat[which];
+    free_csr(A);
+    A.n_rows = n_rows; A.n_cols = n_cols; A.nnz = nnz;
+    // validate what the kernels assume: monotone row_ptr, columns inside [0, n_cols)
+    for (int i = 0; i < n_rows; ++i) if (row_ptr[i + 1] < row_ptr[i]) FAIL(h, ITS_EINVAL, "row_ptr not monotone");
+    for (int64_t k = 0; k < nnz; ++k) if (col[k] < 0 || col[k] >= n_cols) FAIL(h, ITS_EINVAL, "column index out of range");
+    if (dalloc(h, &A.row_ptr, (size_t)n_rows + 1) || dalloc(h, &A.col, (size_t)nnz + 8) || dalloc(h, &A.val, (size_t)nnz + 8))
+        return ITS_EHIP;
+    HIPCHK(h, hipMemcpy(A.row_ptr, row_ptr, ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(A.col + nnz, 0, 8 * sizeof(int)));
+    HIPCHK(h, hipMemset(A.val + nnz, 0, 8 * sizeof(double)));
+    if (nnz) {
+        HIPCHK(h, hipMemcpy(A.col, col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(A.val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    std::vector<int> blk;
+    build_stream_plan(n_rows, row_ptr, blk);
+    A.n_blocks = (int)blk.size() - 1;
+    if (dalloc(h, &A.blk_row, blk.size())) return ITS_EHIP;
+    HIPCHK(h, hipMemcpy(A.blk_row, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+    A.lanes_per_row = pick_lanes_per_row(n_rows, nnz);
+    if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; }
+    h->have[which] = true;
+    if (which == ITS_MAT_A) { h->fmt = format; h->setup_done = false; h->residual_done = false; }
+    return ITS_OK;
+}
+
+extern "C" int its_upload_crs(its_handle *h, int which, int n_rows, int n_cols, int64_t nnz,
+                              const int *row_ptr, const int *col, const double *val, int format)
+{
+    if (!h) return ITS_EINVAL;
+    if (format < ITS_FMT_CSR_EXACT || format > ITS_FMT_SELL) FAIL(h, ITS_EINVAL, "unknown format");
+    int rc = its_upload_csr_local(h, which, n_rows, n_cols, nnz, row_ptr, col, val, format);
+    if (rc == ITS_OK && which == ITS_MAT_A) { h->n = n_rows; h->n_ext = n_cols; }
+    return rc;
+}
+
+extern "C" int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occ, int *n_row_blocks)
+{
+    if (!h || which < 0 || which > 2 || !h->have[which]) return ITS_EINVAL;
+    (void)format;
+    const CsrDev &A = h->mat[which];
+    if (lanes_per_row) *lanes_per_row = A.lanes_per_row;
+    if (sell_occ) *sell_occ = A.sell_elems ? (double)A.nnz / (double)A.sell_elems : 0.0;
+    if (n_row_blocks) *n_row_blocks = A.n_blocks;
+    return ITS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+static int spmv_dispatch(its_handle *h, const CsrDev &A, const SpmvArgs &a, int epi, int format)
+{
+    if (epi >= EPI_JACOBI_SHIPPED || format == ITS_FMT_CSR_EXACT) launch_spmv_exact(A, a, epi, h->stream);
+    else if (format == ITS_FMT_CSR_VECTOR) launch_spmv_vector(A, a, epi, h->stream);
+    else if (format == ITS_FMT_SELL) {
+        if (!A.sell_val && A.nnz) FAIL(h, ITS_ESTATE, "matrix was not uploaded with ITS_FMT_SELL");
+        launch_spmv_sell(A, a, epi, h->stream);
+    } else FAIL(h, ITS_EINVAL, "unknown format");
+    HIPCHK(h, hipGetLastError());
+    return ITS_OK;
+}
+
+// multi-GPU hooks (its_dist.hip); no-ops / identity on one GPU
+int  its_dist_active(const its_handle *h);
+int  its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi);           // halo exchange + SpMV
+int  its_dist_allreduce(its_handle *h, double *dev, int count, int op);  // 0 sum, 1 max (in place)
+
+// y = A x (+ epilogue) for the solver loops: halo exchange first when row-partitioned.
+static int solver_spmv(its_handle *h, const SpmvArgs &a, int epi)
+{
+    if (its_dist_active(h)) return its_dist_spmv(h, a, epi);
+    return spmv_dispatch(h, h->mat[ITS_MAT_A], a, epi, h->fmt);
+}
+
+// partials -> one device scalar (all-reduced across ranks when distributed)
+static int finish_scalar(its_handle *h, const double *part, double *out, int mode)
+{
+    if (!its_dist_active(h)) { launch_reduce_finalize(part, out, mode, h->stream); return ITS_OK; }
+    launch_reduce_finalize(part, out, mode == FIN_MAX ? FIN_MAX : FIN_SUM, h->stream);
+    int rc = its_dist_allreduce(h, out, 1, mode == FIN_MAX ? 1 : 0);
+    if (rc) return rc;
+    if (mode == FIN_SQRT) launch_sqrt_scalar(out, out, h->stream);
+    return ITS_OK;
+}
+
+extern "C" int its_upload_vectors(its_handle *h, const double *D, const double *b, const double *x0, int n)
+{
+    if (!h || !D || !b || !x0) return ITS_EINVAL;
+    if (!h->have[ITS_MAT_A] || n != h->n) FAIL(h, ITS_ESTATE, "upload the matrix first; n must equal its row count");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t ne = (size_t)std::max(h->n_ext, h->n);
+    dfree(h->D); dfree(h->b); dfree(h->r); dfree(h->tmp); dfree(h->x_a); dfree(h->x_b); dfree(h->x);
+    if (dalloc(h, &h->D, n) || dalloc(h, &h->b, n) || dalloc(h, &h->r, ne) || dalloc(h, &h->tmp, ne) ||
+        dalloc(h, &h->x_a, ne) || dalloc(h, &h->x_b, ne) || dalloc(h, &h->x, ne)) return ITS_EHIP;
+    // allocate_cpu_solver_structs zero-fills everything (solver.hpp:220-280)
+    for (double *v : {h->r, h->tmp, h->x_a, h->x_b, h->x}) HIPCHK(h, hipMemsetAsync(v, 0, ne * sizeof(double), h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->D, D, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->b, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->x_a, x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));   // x_old
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->setup_done = false; h->residual_done = false;
+    return ITS_OK;
+}
+
+extern "C" int its_init_residual(its_handle *h, double *r0_inf, double *r0_two)
+{
+    if (!h) return ITS_EINVAL;
+    if (!h->x_a) FAIL(h, ITS_ESTATE, "its_upload_vectors first");
+    HIPCHK(h, hipSetDevice(h->device));
+    SpmvArgs a; a.x = h->x_a; a.y = h->r; a.b = h->b; a.part_sum = h->part[0]; a.part_max = h->part[1];
+    int rc = solver_spmv(h, a, EPI_RESIDUAL);                       // solver.hpp:852-854
+    if (rc) return rc;
+    if ((rc = finish_scalar(h, h->part[0], h->sc + SC_TMP, FIN_SQRT))) return rc;
+    if ((rc = finish_scalar(h, h->part[1], h->sc + SC_TMP + 1, FIN_MAX))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->pinned, h->sc + SC_TMP, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (r0_two) *r0_two = h->pinned[0];
+    if (r0_inf) *r0_inf = h->pinned[1];
+    h->residual_done = true;
+    return ITS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// triangular-sweep schedule: level(i) = 1 + max level(j) over strictly-lower entries of row i
+// ---------------------------------------------------------------------------------------
+static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc)
+{
+    std::vector<int> lev(n, 0);
+    int nl = 0;
+    for (int i = 0; i < n; ++i) {
+        int l = 0;
+        for (int k = Lp[i]; k < Lp[i + 1]; ++k) l = std::max(l, lev[Lc[k]] + 1);
+        lev[i] = l; nl = std::max(nl, l + 1);
+    }
+    if (n == 0) nl = 0;
+    h->n_levels = nl;
+    h->level_ptr.assign(nl + 1, 0);
+    for (int i = 0; i < n; ++i) ++h->level_ptr[lev[i] + 1];
+    for (int l = 0; l < nl; ++l) h->level_ptr[l + 1] += h->level_ptr[l];
+    std::vector<int> rows(n), fill(h->level_ptr.begin(), h->level_ptr.end() - (nl ? 1 : 0));
+    for (int i = 0; i < n; ++i) rows[fill[lev[i]]++] = i;            // ascending row inside a level
+    dfree(h->level_rows);
+    if (dalloc(h, &h->level_rows, n)) return ITS_EHIP;
+    HIPCHK(h, hipMemcpy(h->level_rows, rows.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    return ITS_OK;
+}
+
+// forward solve (D+L) x = rhs, level by level (kernels.hpp:451-473); x may alias rhs
+static int sweep(its_handle *h, double *x, const double *rhs)
+{
+    const CsrDev &L = h->mat[ITS_MAT_L];
+    for (int l = 0; l < h->n_levels; ++l) {
+        const int cnt = h->level_ptr[l + 1] - h->level_ptr[l];
+        launch_sweep_level(L, h->level_rows + h->level_ptr[l], cnt, x, rhs, h->D, h->stream);
+    }
+    HIPCHK(h, hipGetLastError());
+    return ITS_OK;
+}
+
+extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precond_kind,
+                                int jacobi_mode, int gs_order)
+{
+    if (!h) return ITS_EINVAL;
+    if (solver_kind < ITS_JACOBI || solver_kind > ITS_GMRES) FAIL(h, ITS_EINVAL, "unknown solver kind");
+    if (!h->residual_done) FAIL(h, ITS_ESTATE, "its_init_residual first (main.cpp:307 precedes :317)");
+    HIPCHK(h, hipSetDevice(h->device));
+    h->solver = solver_kind; h->precond = precond_kind; h->jacobi_mode = jacobi_mode; h->gs_order = gs_order;
+    const int n = h->n;
+    const size_t ne = (size_t)std::max(h->n_ext, n);
+    const bool need_L = solver_kind == ITS_GAUSS_SEIDEL || (solver_kind == ITS_GMRES && precond_kind == ITS_PRECOND_GS);
+    if (need_L) {
+        if (its_dist_active(h)) FAIL(h, ITS_EUNSUPPORTED, "triangular sweeps are single-GPU in this round");
+        if (!h->have[ITS_MAT_L] || (solver_kind == ITS_GAUSS_SEIDEL && !h->have[ITS_MAT_U]))
+            FAIL(h, ITS_ESTATE, "upload crs_L / crs_U first (gauss_seidel.hpp:433-450)");
+        const CsrDev &L = h->mat[ITS_MAT_L];
+        std::vector<int> Lp(n + 1), Lc((size_t)L.nnz);
+        HIPCHK(h, hipMemcpy(Lp.data(), L.row_ptr, (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        if (L.nnz) HIPCHK(h, hipMemcpy(Lc.data(), L.col, (size_t)L.nnz * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) for (int k = Lp[i]; k < Lp[i + 1]; ++k)
+            if (Lc[k] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
+        int rc = build_levels(h, n, Lp.data(), Lc.data());
+        if (rc) return rc;
+    }
+    if (solver_kind == ITS_JACOBI && jacobi_mode == ITS_JACOBI_SHIPPED) {
+        // The shipped sweep gathers from x_new, which is still all zeros on the first trip
+        // (solver.hpp:225); x_old = x0 is overwritten by the swapped SpMV (jacobi.hpp:191)
+        // before anything reads it.  x_a plays x_new here.
+        HIPCHK(h, hipMemsetAsync(h->x_a, 0, ne * sizeof(double), h->stream));
+    }
+    if (solver_kind == ITS_CG) {                                     // cg.hpp:326-352
+        dfree(h->p);
+        if (dalloc(h, &h->p, ne)) return ITS_EHIP;
+        HIPCHK(h, hipMemsetAsync(h->p, 0, ne * sizeof(double), h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->p, h->r, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        // rr = r0 . r0 (cg.hpp:148 computes it at the top of the first trip)
+        launch_dot_partials(h->r, h->r, n, h->part[0], h->stream);
+        h->rr_slot = 0;
+        int rc = finish_scalar(h, h->part[0], h->sc + SC_RR0, FIN_SUM);
+        if (rc) return rc;
+    } else if (solver_kind == ITS_GMRES) {                           // gmres.hpp:672-786
+        if (restart_len < 1) FAIL(h, ITS_EINVAL, "restart_len < 1");
+        const int m = h->m = restart_len;
+        dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
+        if (dalloc(h, &h->V, ne * (size_t)(m + 1)) || dalloc(h, &h->hcol_dev, m + 2) || dalloc(h, &h->y_dev, m + 1)) return ITS_EHIP;
+        h->Rm.assign((size_t)(m + 1) * m, 0.0); h->g.assign(m + 1, 0.0);
+        h->cs.assign(m, 0.0); h->sn.assign(m, 0.0); h->hcol.assign(m + 2, 0.0);
+        h->restart_count = 0;
+        // beta = ||r||, V[0] = r * (1/beta)   (gmres.hpp:734-736,768-771)
+        launch_dot_partials(h->r, h->r, n, h->part[0], h->stream);
+        int rc = finish_scalar(h, h->part[0], h->sc + SC_TMP, FIN_SUM);
+        if (rc) return rc;
+        launch_mgs_normalize(h->V, h->r, h->sc + SC_TMP, 1, h->hcol_dev, n, h->stream);
+        HIPCHK(h, hipMemcpyAsync(h->pinned, h->hcol_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->beta = h->pinned[0];
+        std::fill(h->g.begin(), h->g.end(), 0.0); h->g[0] = h->beta;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->setup_done = true;
+    h->last_residual = 0.0;
+    return ITS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// one trip of each method, enqueued on h->stream; the residual scalar lands in res_out (device)
+// ---------------------------------------------------------------------------------------
+static int trip_cg(its_handle *h, double *res_out)
+{
+    const int n = h->n;
+    double *rr_in = h->sc + (h->rr_slot ? SC_RR1 : SC_RR0);
+    double *rr_out = h->sc + (h->rr_slot ? SC_RR0 : SC_RR1);
+    SpmvArgs a; a.x = h->p; a.y = h->tmp; a.dotv = h->p; a.part_sum = h->part[0];
+    int rc = solver_spmv(h, a, EPI_STORE);                            // cg.hpp:128,160
+    if (rc) return rc;
+    const double *pq = h->part[0]; int pq_scalar = 0;
+    if (its_dist_active(h)) {
+        if ((rc = finish_scalar(h, h->part[0], h->sc + SC_PQ, FIN_SUM))) return rc;
+        pq = h->sc + SC_PQ; pq_scalar = 1;
+    }
+    launch_cg_update_xr(h->x_a, h->r, h->p, h->tmp, n, pq, pq_scalar, rr_in, h->sc, h->part[1], h->stream);
+    const double *rr = h->part[1]; int rr_scalar = 0;
+    if (its_dist_active(h)) {
+        if ((rc = finish_scalar(h, h->part[1], h->sc + SC_TMP, FIN_SUM))) return rc;
+        rr = h->sc + SC_TMP; rr_scalar = 1;
+    }
+    launch_cg_update_p(h->p, h->r, n, rr, rr_scalar, rr_in, rr_out, h->sc, res_out, h->stream);
+    h->rr_slot ^= 1;
+    HIPCHK(h, hipGetLastError());
+    return ITS_OK;
+}
+
+static int trip_jacobi(its_handle *h, double *res_out)
+{
+    // x_a = x_old (and, in SHIPPED mode, the reference's x_new before the trip: after
+    // exchange_arrays both hold the same values, solver.hpp:796-798); x_b receives the new iterate.
+    SpmvArgs a; a.y = h->x_b; a.b = h->b; a.D = h->D;
+    int rc;
+    if (h->jacobi_mode == ITS_JACOBI_SHIPPED) {
+        a.x = h->x_a;
+        rc = solver_spmv(h, a, EPI_JACOBI_SHIPPED);
+    } else {
+        a.x = h->x_a;
+        rc = solver_spmv(h, a, EPI_JACOBI_REF);
+    }
+    if (rc) return rc;
+    // record_residual_norm: r = b - A x_new, 2-norm (utility_funcs.hpp:423-426)
+    SpmvArgs q; q.x = h->x_b; q.y = h->r; q.b = h->b; q.part_sum = h->part[0];
+    if ((rc = solver_spmv(h, q, EPI_RESIDUAL))) return rc;
+    if ((rc = finish_scalar(h, h->part[0], res_out, FIN_SQRT))) return rc;
+    std::swap(h->x_a, h->x_b);                                        // exchange_arrays
+    return ITS_OK;
+}
+
+static int trip_gs(its_handle *h, double *res_out)
+{
+    SpmvArgs u; u.x = h->x; u.y = h->tmp; u.b = h->b;
+    int rc = spmv_dispatch(h, h->mat[ITS_MAT_U], u, EPI_GS_RHS, ITS_FMT_CSR_EXACT);   // gauss_seidel.hpp:144,177
+    if (rc) return rc;
+    if ((rc = sweep(h, h->x, h->tmp))) return rc;                                      // :227
+    SpmvArgs q; q.x = h->x; q.y = h->r; q.b = h->b; q.part_sum = h->part[0];
+    if ((rc = solver_spmv(h, q, EPI_RESIDUAL))) return rc;                             // utility_funcs.hpp:444-447
+    return finish_scalar(h, h->part[0], res_out, FIN_SQRT);
+}
+
+// GMRES trip: device part (SpMV + MGS) then the host Givens update.  Needs a host sync.
+static int trip_gmres(its_handle *h, int iter_count, double *res_host)
+{
+    const int n = h->n, m = h->m;
+    const size_t ld = (size_t)std::max(h->n_ext, n);
+    const int k = iter_count - h->restart_count * m;                  // gmres.hpp:113
+    if (k < 0 || k >= m) FAIL(h, ITS_ESTATE, "GMRES inner index out of range: restart missing?");
+    double *w = h->tmp;
+    SpmvArgs a; a.x = h->V + (size_t)k * ld; a.y = w;
+    int rc = solver_spmv(h, a, EPI_STORE);                            // gmres.hpp:234
+    if (rc) return rc;
+    if (h->precond == ITS_PRECOND_GS) { if ((rc = sweep(h, w, w))) return rc; }   // gmres.hpp:251
+    const bool dist = its_dist_active(h);
+    // MGS (gmres.hpp:269-329): step j finishes w -= h_{j-1} v_{j-1} and starts h_j = w . v_j
+    const double *prev_part = nullptr; int prev_scalar = 0;
+    for (int j = 0; j <= k + 1; ++j) {
+        double *next_part = h->part[j & 1];
+        const double *v_prev = j > 0 ? h->V + (size_t)(j - 1) * ld : nullptr;
+        const double *v_next = j <= k ? h->V + (size_t)j * ld : nullptr;   // j == k+1: w . w
+        launch_mgs_step(w, v_prev, prev_part, prev_scalar, v_next, next_part,
+                        j > 0 ? h->hcol_dev + (j - 1) : nullptr, n, h->stream);
+        prev_part = next_part; prev_scalar = 0;
+        if (dist) {
+            double *s = h->sc + SC_TMP + (j & 1);
+            if ((rc = finish_scalar(h, next_part, s, FIN_SUM))) return rc;
+            prev_part = s; prev_scalar = 1;
+        }
+    }
+    // H[k+1,k] = ||w||, V[k+1] = w / H[k+1,k]   (gmres.hpp:359,389)
+    launch_mgs_normalize(h->V + (size_t)(k + 1) * ld, w, prev_part, prev_scalar, h->hcol_dev + (k + 1), n, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->pinned, h->hcol_dev, (size_t)(k + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // ---- host: Givens least squares (gmres.hpp:427-658) as O(k) rotation updates.  The
+    // reference forms Q = J_k...J_0 and R = Q H with dense products; applying the stored
+    // rotations to the new column gives the same R[:,k] and g up to round-off.
+    double *hc = h->hcol.data();
+    for (int i = 0; i <= k + 1; ++i) hc[i] = h->pinned[i];
+    for (int i = 0; i < k; ++i) {
+        const double t0 = h->cs[i] * hc[i] + h->sn[i] * hc[i + 1];
+        const double t1 = -h->sn[i] * hc[i] + h->cs[i] * hc[i + 1];
+        hc[i] = t0; hc[i + 1] = t1;
+    }
+    const double denom = std::sqrt(hc[k] * hc[k] + hc[k + 1] * hc[k + 1]);   // gmres.hpp:484-485
+    const double c = hc[k] / denom, s = hc[k + 1] / denom;                   // :487-488
+    h->cs[k] = c; h->sn[k] = s;
+    hc[k] = c * hc[k] + s * hc[k + 1]; hc[k + 1] = 0.0;
+    for (int i = 0; i <= k; ++i) h->Rm[(size_t)k * (m + 1) + i] = hc[i];
+    h->g[k + 1] = -s * h->g[k];
+    h->g[k] = c * h->g[k];
+    *res_host = std::fabs(h->g[k + 1]);                                      // :658
+    return ITS_OK;
+}
+
+// gmres_get_x (gmres.hpp:845-978): back-substitute on the host, x = x0 + V^T y on the device
+static int gmres_get_x(its_handle *h, double *x_out, const double *x0, int iter_count)
+{
+    const int n = h->n, m = h->m;
+    const size_t ld = (size_t)std::max(h->n_ext, n);
+    const int k = iter_count - h->restart_count * m;                  // :880
+    std::vector<double> y(m + 1, 0.0);
+    for (int row = k; row >= 0; --row) {                              // :901-916
+        double sum = 0.0;
+        for (int c = row + 1; c <= k; ++c) sum = std::fma(h->Rm[(size_t)c * (m + 1) + row], y[c], sum);
+        y[row] = (h->g[row] - sum) / h->Rm[(size_t)row * (m + 1) + row];
+    }
+    const int terms = std::max(0, k + 1);
+    for (int i = 0; i < m + 1; ++i) h->pinned[1024 + i] = y[i];
+    HIPCHK(h, hipMemcpyAsync(h->y_dev, h->pinned + 1024, (size_t)(m + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    launch_gmres_update_x(x_out, x0, h->V, (int64_t)ld, h->y_dev, terms, n, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // pinned y buffer is reused
+    return ITS_OK;
+}
+
+static int check_ready(its_handle *h)
+{
+    if (!h) return ITS_EINVAL;
+    if (!h->setup_done) FAIL(h, ITS_ESTATE, "its_solver_setup first");
+    if (hipSetDevice(h->device) != hipSuccess) FAIL(h, ITS_EHIP, "hipSetDevice");
+    return ITS_OK;
+}
+
+extern "C" int its_iterate(its_handle *h, int iter_count, double *residual_norm)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!residual_norm) return ITS_EINVAL;
+    if (h->solver == ITS_GMRES) {
+        rc = trip_gmres(h, iter_count, residual_norm);
+        if (rc == ITS_OK) h->last_residual = *residual_norm;
+        return rc;
+    }
+    double *res = h->sc + SC_RES;
+    if (h->solver == ITS_CG) rc = trip_cg(h, res);
+    else if (h->solver == ITS_JACOBI) rc = trip_jacobi(h, res);
+    else rc = trip_gs(h, res);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->pinned, res, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *residual_norm = h->last_residual = h->pinned[0];
+    return ITS_OK;
+}
+
+extern "C" int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double *residuals)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (n_trips < 1 || !residuals) return ITS_EINVAL;
+    if (h->solver == ITS_GMRES) {
+        // GMRES needs its H column on the host every trip; time the whole region all the same
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        for (int i = 0; i < n_trips; ++i) {
+            const int it = iter_count0 + i;
+            if ((rc = trip_gmres(h, it, &residuals[i]))) return rc;
+            h->last_residual = residuals[i];
+            if ((it + 1) % h->m == 0 && i + 1 < n_trips) { if ((rc = its_gmres_restart(h, it))) return rc; }
+        }
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipEventSynchronize(h->ev1));
+        HIPCHK(h, hipEventElapsedTime(&h->last_region_ms, h->ev0, h->ev1));
+        return ITS_OK;
+    }
+    if (n_trips > h->res_cap) {
+        dfree(h->res_dev);
+        if (dalloc(h, &h->res_dev, n_trips)) return ITS_EHIP;
+        h->res_cap = n_trips;
+    }
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < n_trips; ++i) {
+        if (h->solver == ITS_CG) rc = trip_cg(h, h->res_dev + i);
+        else if (h->solver == ITS_JACOBI) rc = trip_jacobi(h, h->res_dev + i);
+        else rc = trip_gs(h, h->res_dev + i);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(residuals, h->res_dev, (size_t)n_trips * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipEventElapsedTime(&h->last_region_ms, h->ev0, h->ev1));
+    h->last_residual = residuals[n_trips - 1];
+    return ITS_OK;
+}
+
+extern "C" int its_gmres_restart(its_handle *h, int iter_count)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->solver != ITS_GMRES) FAIL(h, ITS_ESTATE, "not a GMRES handle");
+    const int n = h->n;
+    // x = x_old + V^T y (solver.hpp:563-590); r = b - A x (:609); precondition (:610)
+    if ((rc = gmres_get_x(h, h->x, h->x_a, iter_count))) return rc;
+    SpmvArgs a; a.x = h->x; a.y = h->r; a.b = h->b; a.part_sum = h->part[0];
+    if ((rc = solver_spmv(h, a, EPI_RESIDUAL))) return rc;
+    const double *nrm_part = h->part[0];
+    if (h->precond == ITS_PRECOND_GS) {
+        if ((rc = sweep(h, h->r, h->r))) return rc;
+        launch_dot_partials(h->r, h->r, n, h->part[1], h->stream);
+        nrm_part = h->part[1];
+    }
+    // beta, V[0] = r / beta, fresh rotations (solver.hpp:621-641 -> gmres.hpp:726-786)
+    if ((rc = finish_scalar(h, nrm_part, h->sc + SC_TMP, FIN_SUM))) return rc;
+    launch_mgs_normalize(h->V, h->r, h->sc + SC_TMP, 1, h->hcol_dev, n, h->stream);
+    HIPCHK(h, hipMemcpyAsync(h->pinned, h->hcol_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    // x_old <- x (solver.hpp:652-655)
+    HIPCHK(h, hipMemcpyAsync(h->x_a, h->x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->beta = h->pinned[0];
+    std::fill(h->g.begin(), h->g.end(), 0.0); h->g[0] = h->beta;
+    std::fill(h->Rm.begin(), h->Rm.end(), 0.0);
+    ++h->restart_count;
+    return ITS_OK;
+}
+
+extern "C" int its_download_x(its_handle *h, double *x_star, int n, int iter_count)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!x_star || n != h->n) return ITS_EINVAL;
+    const double *src = nullptr;
+    if (h->solver == ITS_JACOBI || h->solver == ITS_CG) src = h->x_a;          // solver.hpp:663-698 (x_old)
+    else if (h->solver == ITS_GAUSS_SEIDEL) src = h->x;                          // :699-708
+    else {                                                                        // :709-725
+        if ((rc = gmres_get_x(h, h->x_b, h->x_a, iter_count - 1))) return rc;
+        src = h->x_b;
+    }
+    HIPCHK(h, hipMemcpyAsync(x_star, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ITS_OK;
+}
+
+extern "C" int its_final_residual(its_handle *h, double *residual_norm)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!residual_norm) return ITS_EINVAL;
+    if (h->solver == ITS_GMRES) { *residual_norm = h->last_residual; return ITS_OK; }
+    double *res = h->sc + SC_RES;
+    if (h->solver == ITS_CG) {
+        // Solver::r after iterate's swap and exchange_arrays' swap (solver.hpp:545,833) is the
+        // buffer that held r_old during the last trip, i.e. the PREVIOUS trip's residual.  The
+        // device keeps one r; the previous norm is sqrt(rr_old) which still sits in the other slot.
+        launch_sqrt_scalar(h->sc + (h->rr_slot ? SC_RR0 : SC_RR1), res, h->stream);
+    } else {
+        const double *xs = h->solver == ITS_JACOBI ? h->x_a : h->x;
+        SpmvArgs q; q.x = xs; q.y = h->r; q.b = h->b; q.part_sum = h->part[0];
+        if ((rc = solver_spmv(h, q, EPI_RESIDUAL))) return rc;
+        if ((rc = finish_scalar(h, h->part[0], res, FIN_SQRT))) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->pinned, res, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *residual_norm = h->pinned[0];
+    return ITS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernels alone
+// ---------------------------------------------------------------------------------------
+extern "C" int its_spmv(its_handle *h, int which, const double *x, double *y, int where, int format)
+{
+    if (!h || which < 0 || which > 2 || !x || !y) return ITS_EINVAL;
+    if (!h->have[which]) FAIL(h, ITS_ESTATE, "matrix not uploaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    const CsrDev &A = h->mat[which];
+    if (where == 1) {
+        SpmvArgs a; a.x = x; a.y = y;
+        int rc = spmv_dispatch(h, A, a, EPI_STORE, format);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return ITS_OK;
+    }
+    double *dx = nullptr, *dy = nullptr;
+    if (dalloc(h, &dx, A.n_cols) || dalloc(h, &dy, A.n_rows)) return ITS_EHIP;
+    HIPCHK(h, hipMemcpyAsync(dx, x, (size_t)A.n_cols * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    SpmvArgs a; a.x = dx; a.y = dy;
+    int rc = spmv_dispatch(h, A, a, EPI_STORE, format);
+    if (rc == ITS_OK) {
+        hipError_t e = hipMemcpyAsync(y, dy, (size_t)A.n_rows * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = ITS_EHIP; }
+    }
+    dfree(dx); dfree(dy);
+    return rc;
+}
+
+extern "C" int its_spmv_timed(its_handle *h, int which, const double *x_dev, double *y_dev, int format, int reps, float *avg_ms)
+{
+    if (!h || which < 0 || which > 2 || !x_dev || !y_dev || reps < 1 || !avg_ms) return ITS_EINVAL;
+    if (!h->have[which]) FAIL(h, ITS_ESTATE, "matrix not uploaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    SpmvArgs a; a.x = x_dev; a.y = y_dev;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) { int rc = spmv_dispatch(h, h->mat[which], a, EPI_STORE, format); if (rc) return rc; }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_region_ms = ms;
+    *avg_ms = ms / reps;
+    return ITS_OK;
+}
+
+extern "C" int its_last_region_ms(its_handle *h, float *ms)
+{
+    if (!h || !ms) return ITS_EINVAL;
+    *ms = h->last_region_ms;
+    return ITS_OK;
+}
+
+static int scalar_out(its_handle *h, double *out)
+{
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->pinned, h->sc + SC_TMP, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *out = h->pinned[0];
+    return ITS_OK;
+}
+
+extern "C" int its_dot(its_handle *h, const double *a, const double *b, int64_t n, double *out)
+{
+    if (!h || !a || !b || !out || n < 0) return ITS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_dot_partials(a, b, n, h->part[2], h->stream);
+    launch_reduce_finalize(h->part[2], h->sc + SC_TMP, FIN_SUM, h->stream);
+    return scalar_out(h, out);
+}
+
+extern "C" int its_nrm2(its_handle *h, const double *v, int64_t n, double *out)
+{
+    if (!h || !v || !out || n < 0) return ITS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_dot_partials(v, v, n, h->part[2], h->stream);
+    launch_reduce_finalize(h->part[2], h->sc + SC_TMP, FIN_SQRT, h->stream);
+    return scalar_out(h, out);
+}
+
+extern "C" int its_norm_inf(its_handle *h, const double *v, int64_t n, double *out)
+{
+    if (!h || !v || !out || n < 0) return ITS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_absmax_partials(v, n, h->part[2], h->stream);
+    launch_reduce_finalize(h->part[2], h->sc + SC_TMP, FIN_MAX, h->stream);
+    return scalar_out(h, out);
+}
+
+extern "C" int its_axpby(its_handle *h, double *out, const double *a, const double *b, int64_t n, double s)
+{
+    if (!h || !out || !a || !b || n < 0) return ITS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_axpby(out, a, b, n, s, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ITS_OK;
+}
+
+extern "C" int its_scale(its_handle *h, double *out, const double *v, double s, int64_t n)
+{
+    if (!h || !out || !v || n < 0) return ITS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_scale(out, v, s, n, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ITS_OK;
+}
+
+extern "C" int its_spltsv(its_handle *h, double *x_dev, const double *rhs_dev)
+{
+    if (!h || !x_dev || !rhs_dev) return ITS_EINVAL;
+    if (!h->have[ITS_MAT_L] || !h->D) FAIL(h, ITS_ESTATE, "needs crs_L and D");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->level_rows) {
+        const CsrDev &L = h->mat[ITS_MAT_L];
+        const int n = L.n_rows;
+        std::vector<int> Lp(n + 1), Lc((size_t)L.nnz);
+        HIPCHK(h, hipMemcpy(Lp.data(), L.row_ptr, (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        if (L.nnz) HIPCHK(h, hipMemcpy(Lc.data(), L.col, (size_t)L.nnz * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) for (int k = Lp[i]; k < Lp[i + 1]; ++k)
+            if (Lc[k] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
+        int rc = build_levels(h, n, Lp.data(), Lc.data());
+        if (rc) return rc;
+    }
+    int rc = sweep(h, x_dev, rhs_dev);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ITS_OK;
+}
+
+extern "C" int its_dev_alloc(its_handle *h, void **p, size_t bytes)
+{
+    if (!h || !p) return ITS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMalloc(p, std::max<size_t>(bytes, 16)));
+    return ITS_OK;
+}
+extern "C" int its_dev_free(its_handle *h, void *p) { if (!h) return ITS_EINVAL; HIPCHK(h, hipFree(p)); return ITS_OK; }
+extern "C" int its_memcpy_h2d(its_handle *h, void *d, const void *s, size_t bytes)
+{ if (!h) return ITS_EINVAL; HIPCHK(h, hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); return ITS_OK; }
+extern "C" int its_memcpy_d2h(its_handle *h, void *d, const void *s, size_t bytes)
+{ if (!h) return ITS_EINVAL; HIPCHK(h, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); return ITS_OK; }
+extern "C" int its_synchronize(its_handle *h) { if (!h) return ITS_EINVAL; HIPCHK(h, hipStreamSynchronize(h->stream)); return ITS_OK; }

@@ -1,0 +1,108 @@
+// its_kernels.h — launch interface between the C ABI (its_api.hip) and the gfx950 kernels.
+// Every launcher enqueues on the given stream and returns immediately (no sync, no malloc).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "its_device.h"
+
+namespace its {
+
+// ---------------------------------------------------------------------------------------
+// CSR "stream" plan: rows are cut into row blocks of at most ITS_BLOCK rows and at most
+// SPMV_NNZ_MAX nonzeros (a single longer row forms a block of its own and is walked in
+// several LDS chunks).  blk_row[nb+1] holds the first row of each block.
+// ---------------------------------------------------------------------------------------
+constexpr int SPMV_NNZ_MAX = 1792;      // 256 rows x 7 nnz; 1792*(8+4) B + row ptrs ≈ 22.6 KB LDS
+
+enum SpmvEpilogue {
+    EPI_STORE = 0,        // y = A x                                  (kernels.hpp:380-409)
+    EPI_RESIDUAL = 1,     // y = b - A x, + sum r^2 and max|r|        (kernels.hpp:670-726)
+    EPI_JACOBI_SHIPPED = 2,  // out = (b - (x - D*(A x)))/D           (jacobi.hpp:191,41-62)
+    EPI_JACOBI_REF = 3,   // out = (b - sum_{j!=i} a_ij x_j)/a_ii     (jacobi.hpp:65-93)
+    EPI_GS_RHS = 4        // y = b - U x                              (gauss_seidel.hpp:144,177)
+};
+
+struct CsrDev {
+    int n_rows = 0, n_cols = 0;
+    int64_t nnz = 0;
+    int *row_ptr = nullptr, *col = nullptr;   // col/val padded by 8 elements for aligned over-read
+    double *val = nullptr;
+    // stream plan
+    int n_blocks = 0;
+    int *blk_row = nullptr;
+    // vector-CSR plan
+    int lanes_per_row = 0;
+    // SELL-64-sigma image
+    int sell_chunks = 0, sell_sigma = 0;
+    int64_t sell_elems = 0;
+    int *sell_chunk_ptr = nullptr, *sell_chunk_len = nullptr, *sell_col = nullptr, *sell_perm = nullptr;
+    double *sell_val = nullptr;
+};
+
+struct SpmvArgs {
+    const double *x = nullptr;     // gathered vector
+    double *y = nullptr;           // output vector
+    const double *b = nullptr;     // rhs for residual / Jacobi / GS epilogues
+    const double *D = nullptr;     // diagonal for EPI_JACOBI_SHIPPED
+    const double *dotv = nullptr;  // if set: part_sum[g] = sum_i (A x)_i * dotv_i   (EPI_STORE only)
+    double *part_sum = nullptr;    // ITS_NPART partial sums (dot, or r^2 for EPI_RESIDUAL)
+    double *part_max = nullptr;    // ITS_NPART partial max|r| (EPI_RESIDUAL, optional)
+    // distributed runs: only rows of this class are processed (0 = all, 1 = interior, 2 = boundary)
+    int row_begin = 0, row_end = -1;
+};
+
+void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
+void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
+void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// BLAS-1.  Reductions write ITS_NPART partials; reduce_finalize turns them into one scalar.
+// ---------------------------------------------------------------------------------------
+enum { FIN_SUM = 0, FIN_SQRT = 1, FIN_MAX = 2 };
+void launch_dot_partials(const double *a, const double *b, int64_t n, double *part, hipStream_t s);
+void launch_absmax_partials(const double *v, int64_t n, double *part, hipStream_t s);
+void launch_reduce_finalize(const double *part, double *out, int mode, hipStream_t s);
+void launch_sqrt_scalar(const double *in, double *out, hipStream_t s);   // out[0] = sqrt(in[0])
+void launch_axpby(double *out, const double *a, const double *b, int64_t n, double sc, hipStream_t s);
+void launch_scale(double *out, const double *v, double sc, int64_t n, hipStream_t s);
+void launch_copy(double *out, const double *v, int64_t n, hipStream_t s);
+void launch_fill(double *out, double v, int64_t n, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// CG (methods/cg.hpp:40-281).  Device scalars live in a small double array `sc`:
+// ---------------------------------------------------------------------------------------
+enum { SC_RR0 = 0, SC_RR1 = 1, SC_PQ = 2, SC_ALPHA = 3, SC_BETA = 4, SC_RES = 5, SC_TMP = 6, SC_COUNT = 16 };
+// x += alpha p ; r -= alpha q ; part_rr = partial sum r^2.   alpha = rr_in[0] / (sum of part_pq)
+// If pq_is_scalar, part_pq[0] already holds the (all-reduced) sum.
+void launch_cg_update_xr(double *x, double *r, const double *p, const double *q, int64_t n,
+                         const double *part_pq, int pq_is_scalar, const double *rr_in, double *sc,
+                         double *part_rr, hipStream_t s);
+// p = r + beta p, beta = rr_new/rr_old[0] ; block 0 stores rr_new -> rr_new[0] (a different
+// slot than rr_old), sqrt(rr_new) -> res_out[0]
+void launch_cg_update_p(double *p, const double *r, int64_t n, const double *part_rr,
+                        int rr_is_scalar, const double *rr_old, double *rr_new, double *sc,
+                        double *res_out, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// GMRES modified Gram-Schmidt (methods/gmres.hpp:269-329,359,389) as fused axpy+dot steps.
+// ---------------------------------------------------------------------------------------
+// w -= h_prev * v_prev (h_prev = sum of part_prev, skipped when v_prev == nullptr);
+// part_next = partial sums of w . v_next (v_next == nullptr: of w . w);  block 0 stores
+// h_prev to h_out[0] when given.
+void launch_mgs_step(double *w, const double *v_prev, const double *part_prev, int prev_is_scalar,
+                     const double *v_next, double *part_next, double *h_out, int64_t n, hipStream_t s);
+// v_out = w * (1/sqrt(sum part_ww)) ; block 0 stores sqrt(sum) to h_out[0]
+void launch_mgs_normalize(double *v_out, const double *w, const double *part_ww, int ww_is_scalar,
+                          double *h_out, int64_t n, hipStream_t s);
+// x = x0 + sum_{k<m} y[k] * V[k*ldv + i], in order k = 0..m-1 (gmres.hpp:940,971-972)
+void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t ldv,
+                           const double *y_dev, int m, int64_t n, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Gauss-Seidel / triangular sweeps (kernels.hpp:451-473) by dependency level or colour.
+// rows[] lists the rows of one level; x[i] = (rhs[i] - sum_j L_ij x_j) / D[i], in-order fma.
+// ---------------------------------------------------------------------------------------
+void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, double *x,
+                        const double *rhs, const double *D, hipStream_t s);
+
+}  // namespace its

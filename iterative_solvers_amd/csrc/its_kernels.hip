@@ -1,0 +1,528 @@
+// its_kernels.hip — hand-written gfx950 kernels for the iterative-solver hot path.
+// All kernels: 256-thread workgroups (4 wavefronts of 64), grid = ITS_NPART workgroups
+// (8 per CU on 256 CUs) walking their share of the work; HBM-bandwidth bound, no MFMA.
+#include "its_kernels.h"
+
+namespace its {
+
+// ======================================================================================
+// SpMV, CSR "stream": bit-exact restatement of spmv_crs_cpu (kernels.hpp:380-409).
+//   * a workgroup owns a contiguous run of row blocks (XCD-aware slot, see xcd_slot);
+//   * per row block the col/val segment is streamed with 16-byte-per-lane coalesced loads
+//     into LDS, then ONE LANE PER ROW walks its row out of LDS in CRS order with one fused
+//     multiply-add per entry starting from 0.0 — the reference's arithmetic exactly;
+//   * x gathers go to L1/L2 (for banded matrices consecutive lanes hit consecutive x).
+// ======================================================================================
+template <int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_stream_kernel(
+    int nb, const int *__restrict__ blk_row, const int *__restrict__ rp,
+    const int *__restrict__ col, const double *__restrict__ val, SpmvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double s_val[SPMV_NNZ_MAX + 8];
+    __shared__ __attribute__((aligned(16))) int s_col[SPMV_NNZ_MAX + 8];
+    __shared__ int s_rp[ITS_BLOCK + 1];
+    __shared__ double s_red[4];
+
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    const int slot = xcd_slot(blockIdx.x, G);
+    const int rb0 = (int)(((int64_t)slot * nb) / G);
+    const int rb1 = (int)(((int64_t)(slot + 1) * nb) / G);
+
+    double lane_sum = 0.0, lane_max = 0.0;
+
+    for (int rb = rb0; rb < rb1; ++rb) {
+        const int rs = blk_row[rb];
+        const int nr = blk_row[rb + 1] - rs;
+        for (int i = t; i <= nr; i += ITS_BLOCK) s_rp[i] = rp[rs + i];
+        __syncthreads();
+        const int a0 = s_rp[0], a1 = s_rp[nr];
+        int my0 = 0, my1 = 0;
+        if (t < nr) { my0 = s_rp[t]; my1 = s_rp[t + 1]; }
+        double acc = 0.0;
+        double diag = 0.0;
+        const int row = rs + t;
+        for (int c0 = a0; c0 < a1; c0 += SPMV_NNZ_MAX) {
+            const int c1 = min(a1, c0 + SPMV_NNZ_MAX);
+            const int base = c0 & ~3;   // 16-byte aligned start for the int4 / double2 streams
+            for (int i = base + 4 * t; i < c1; i += 4 * ITS_BLOCK) {
+                const int4 cc = *reinterpret_cast<const int4 *>(col + i);
+                const double2 v0 = *reinterpret_cast<const double2 *>(val + i);
+                const double2 v1 = *reinterpret_cast<const double2 *>(val + i + 2);
+                const int o = i - base;
+                *reinterpret_cast<int4 *>(s_col + o) = cc;
+                *reinterpret_cast<double2 *>(s_val + o) = v0;
+                *reinterpret_cast<double2 *>(s_val + o + 2) = v1;
+            }
+            __syncthreads();
+            if (t < nr) {
+                const int j0 = max(my0, c0) - base, j1 = min(my1, c1) - base;
+                for (int j = j0; j < j1; ++j) {
+                    const int c = s_col[j];
+                    const double v = s_val[j];
+                    if (EPI == EPI_JACOBI_REF) {
+                        if (c == row) diag = v;
+                        else acc = fma(v, a.x[c], acc);
+                    } else {
+                        acc = fma(v, a.x[c], acc);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (a0 == a1) __syncthreads();   // keep s_rp stable until every lane has read it
+        if (t < nr) {
+            if (EPI == EPI_STORE) {
+                a.y[row] = acc;
+                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
+            } else if (EPI == EPI_RESIDUAL) {
+                const double r = a.b[row] - acc;
+                a.y[row] = r;
+                lane_sum = fma(r, r, lane_sum);
+                lane_max = fmax(lane_max, fabs(r));
+            } else if (EPI == EPI_JACOBI_SHIPPED) {
+                const double d = a.D[row];
+                const double adj = fma(-d, acc, a.x[row]);
+                a.y[row] = (a.b[row] - adj) / d;
+            } else if (EPI == EPI_JACOBI_REF) {
+                a.y[row] = (a.b[row] - acc) / diag;
+            } else if (EPI == EPI_GS_RHS) {
+                a.y[row] = fma(-1.0, acc, a.b[row]);
+            }
+        }
+    }
+    if (DOT || EPI == EPI_RESIDUAL) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) a.part_sum[blockIdx.x] = bs;
+        if (EPI == EPI_RESIDUAL && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) a.part_max[blockIdx.x] = bm;
+        }
+    }
+}
+
+void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s)
+{
+    dim3 g(ITS_NPART), b(ITS_BLOCK);
+#define ITS_LAUNCH(E, D) \
+    hipLaunchKernelGGL((spmv_stream_kernel<E, D>), g, b, 0, s, A.n_blocks, A.blk_row, A.row_ptr, A.col, A.val, a)
+    switch (epi) {
+    case EPI_STORE: if (a.dotv) ITS_LAUNCH(EPI_STORE, true); else ITS_LAUNCH(EPI_STORE, false); break;
+    case EPI_RESIDUAL: ITS_LAUNCH(EPI_RESIDUAL, false); break;
+    case EPI_JACOBI_SHIPPED: ITS_LAUNCH(EPI_JACOBI_SHIPPED, false); break;
+    case EPI_JACOBI_REF: ITS_LAUNCH(EPI_JACOBI_REF, false); break;
+    case EPI_GS_RHS: ITS_LAUNCH(EPI_GS_RHS, false); break;
+    }
+#undef ITS_LAUNCH
+}
+
+// ======================================================================================
+// SpMV, vector-CSR: LPR = 2^k lanes cooperate on one row (chosen from the row-length
+// histogram), partial sums combined with a butterfly inside the lane group.  Direct
+// coalesced loads, no LDS.  Reordered summation: 1e-12 relative to the exact variant.
+// ======================================================================================
+template <int LPR, int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_vector_kernel(
+    int n_rows, const int *__restrict__ rp, const int *__restrict__ col,
+    const double *__restrict__ val, SpmvArgs a)
+{
+    __shared__ double s_red[4];
+    constexpr int ROWS_PER_BLOCK = ITS_BLOCK / LPR;
+    const int t = threadIdx.x;
+    const int sub = t & (LPR - 1);
+    const int G = gridDim.x;
+    const int slot = xcd_slot(blockIdx.x, G);
+    const int64_t n_groups = ((int64_t)n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const int64_t g0 = (slot * n_groups) / G, g1 = ((slot + 1) * n_groups) / G;
+    double lane_sum = 0.0, lane_max = 0.0;
+    for (int64_t grp = g0; grp < g1; ++grp) {
+        const int row = (int)(grp * ROWS_PER_BLOCK) + t / LPR;
+        double acc = 0.0;
+        if (row < n_rows) {
+            const int j0 = rp[row], j1 = rp[row + 1];
+            for (int j = j0 + sub; j < j1; j += LPR) acc = fma(val[j], a.x[col[j]], acc);
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, ITS_WAVE);
+        if (row < n_rows && sub == 0) {
+            if (EPI == EPI_STORE) {
+                a.y[row] = acc;
+                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
+            } else if (EPI == EPI_RESIDUAL) {
+                const double r = a.b[row] - acc;
+                a.y[row] = r;
+                lane_sum = fma(r, r, lane_sum);
+                lane_max = fmax(lane_max, fabs(r));
+            }
+        }
+    }
+    if (DOT || EPI == EPI_RESIDUAL) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) a.part_sum[blockIdx.x] = bs;
+        if (EPI == EPI_RESIDUAL && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) a.part_max[blockIdx.x] = bm;
+        }
+    }
+}
+
+template <int LPR>
+static void launch_vec_lpr(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s)
+{
+    dim3 g(ITS_NPART), b(ITS_BLOCK);
+    if (epi == EPI_RESIDUAL)
+        hipLaunchKernelGGL((spmv_vector_kernel<LPR, EPI_RESIDUAL, false>), g, b, 0, s, A.n_rows, A.row_ptr, A.col, A.val, a);
+    else if (a.dotv)
+        hipLaunchKernelGGL((spmv_vector_kernel<LPR, EPI_STORE, true>), g, b, 0, s, A.n_rows, A.row_ptr, A.col, A.val, a);
+    else
+        hipLaunchKernelGGL((spmv_vector_kernel<LPR, EPI_STORE, false>), g, b, 0, s, A.n_rows, A.row_ptr, A.col, A.val, a);
+}
+
+void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s)
+{
+    switch (A.lanes_per_row) {
+    case 2: launch_vec_lpr<2>(A, a, epi, s); break;
+    case 4: launch_vec_lpr<4>(A, a, epi, s); break;
+    case 8: launch_vec_lpr<8>(A, a, epi, s); break;
+    case 16: launch_vec_lpr<16>(A, a, epi, s); break;
+    case 32: launch_vec_lpr<32>(A, a, epi, s); break;
+    default: launch_vec_lpr<64>(A, a, epi, s); break;
+    }
+}
+
+// ======================================================================================
+// SpMV, SELL-64-sigma: one wavefront per chunk of 64 (sorted) rows, column-major inside the
+// chunk (values[chunk_ptr + j*64 + lane], CUDA_tests/helpers/utilities.cpp:321-337), so every
+// load is one fully coalesced 512-byte / 256-byte wave access.  perm[] maps chunk row -> row.
+// ======================================================================================
+template <int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_sell_kernel(
+    int n_rows, int n_chunks, const int *__restrict__ chunk_ptr, const int *__restrict__ chunk_len,
+    const int *__restrict__ scol, const double *__restrict__ sval, const int *__restrict__ perm,
+    SpmvArgs a)
+{
+    __shared__ double s_red[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int G = gridDim.x;
+    const int slot = xcd_slot(blockIdx.x, G);
+    const int64_t n_grp = ((int64_t)n_chunks + 3) / 4;      // 4 chunks (waves) per workgroup step
+    const int64_t g0 = (slot * n_grp) / G, g1 = ((slot + 1) * n_grp) / G;
+    double lane_sum = 0.0, lane_max = 0.0;
+    for (int64_t grp = g0; grp < g1; ++grp) {
+        const int ch = (int)(grp * 4) + w;
+        if (ch < n_chunks) {
+            const int64_t cs = chunk_ptr[ch];
+            const int len = chunk_len[ch];
+            double acc = 0.0;
+            for (int j = 0; j < len; ++j) {
+                const int64_t idx = cs + (int64_t)j * 64 + lane;
+                acc = fma(sval[idx], a.x[scol[idx]], acc);
+            }
+            const int row = perm[ch * 64 + lane];
+            if (row >= 0 && row < n_rows) {
+                if (EPI == EPI_STORE) {
+                    a.y[row] = acc;
+                    if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
+                } else if (EPI == EPI_RESIDUAL) {
+                    const double r = a.b[row] - acc;
+                    a.y[row] = r;
+                    lane_sum = fma(r, r, lane_sum);
+                    lane_max = fmax(lane_max, fabs(r));
+                }
+            }
+        }
+    }
+    if (DOT || EPI == EPI_RESIDUAL) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) a.part_sum[blockIdx.x] = bs;
+        if (EPI == EPI_RESIDUAL && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) a.part_max[blockIdx.x] = bm;
+        }
+    }
+}
+
+void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s)
+{
+    dim3 g(ITS_NPART), b(ITS_BLOCK);
+#define ITS_LAUNCH(E, D) \
+    hipLaunchKernelGGL((spmv_sell_kernel<E, D>), g, b, 0, s, A.n_rows, A.sell_chunks, A.sell_chunk_ptr, \
+                       A.sell_chunk_len, A.sell_col, A.sell_val, A.sell_perm, a)
+    if (epi == EPI_RESIDUAL) ITS_LAUNCH(EPI_RESIDUAL, false);
+    else if (a.dotv) ITS_LAUNCH(EPI_STORE, true);
+    else ITS_LAUNCH(EPI_STORE, false);
+#undef ITS_LAUNCH
+}
+
+// ======================================================================================
+// BLAS-1.  Grid-stride over pairs (16 B per lane) when the operands are 16-byte aligned,
+// scalar tail otherwise.  Reductions: thread sum -> wave butterfly -> 4-wave LDS sum ->
+// partial[blockIdx]; the order is fixed, so results are reproducible run to run.
+// ======================================================================================
+__device__ __forceinline__ bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+__global__ __launch_bounds__(ITS_BLOCK) void dot_partials_kernel(
+    const double *__restrict__ a, const double *__restrict__ b, int64_t n, double *__restrict__ part)
+{
+    __shared__ double s_red[4];
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t n2 = (al16(a) && al16(b)) ? n / 2 : 0;
+    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
+    for (int64_t i = tid; i < n2; i += nth) {
+        const double2 u = a2[i], v = b2[i];
+        s0 = fma(u.x, v.x, s0);
+        s1 = fma(u.y, v.y, s1);
+    }
+    for (int64_t i = 2 * n2 + tid; i < n; i += nth) s0 = fma(a[i], b[i], s0);
+    const double bs = block_sum(s0 + s1, s_red);
+    if (threadIdx.x == 0) part[blockIdx.x] = bs;
+}
+
+__global__ __launch_bounds__(ITS_BLOCK) void absmax_partials_kernel(
+    const double *__restrict__ v, int64_t n, double *__restrict__ part)
+{
+    __shared__ double s_red[4];
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    double m = 0.0;
+    for (int64_t i = tid; i < n; i += nth) m = fmax(m, fabs(v[i]));
+    const double bm = block_max(m, s_red);
+    if (threadIdx.x == 0) part[blockIdx.x] = bm;
+}
+
+__global__ __launch_bounds__(ITS_BLOCK) void reduce_finalize_kernel(
+    const double *__restrict__ part, double *__restrict__ out, int mode)
+{
+    __shared__ double s_red[4];
+    double r;
+    if (mode == FIN_MAX) r = max_partials(part, s_red);
+    else {
+        r = sum_partials(part, s_red);
+        if (mode == FIN_SQRT) r = sqrt(r);
+    }
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+__global__ void sqrt_scalar_kernel(const double *in, double *out) { out[0] = sqrt(in[0]); }
+
+__global__ __launch_bounds__(ITS_BLOCK) void axpby_kernel(
+    double *__restrict__ out, const double *__restrict__ a, const double *__restrict__ b, int64_t n, double sc)
+{
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    int64_t n2 = (al16(a) && al16(b) && al16(out)) ? n / 2 : 0;
+    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
+    double2 *o2 = reinterpret_cast<double2 *>(out);
+    for (int64_t i = tid; i < n2; i += nth) {
+        const double2 u = a2[i], v = b2[i];
+        double2 o; o.x = fma(sc, v.x, u.x); o.y = fma(sc, v.y, u.y);
+        o2[i] = o;
+    }
+    for (int64_t i = 2 * n2 + tid; i < n; i += nth) out[i] = fma(sc, b[i], a[i]);
+}
+
+__global__ __launch_bounds__(ITS_BLOCK) void scale_kernel(
+    double *__restrict__ out, const double *__restrict__ v, double sc, int64_t n)
+{
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    for (int64_t i = tid; i < n; i += nth) out[i] = v[i] * sc;
+}
+
+__global__ __launch_bounds__(ITS_BLOCK) void fill_kernel(double *__restrict__ out, double v, int64_t n)
+{
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    for (int64_t i = tid; i < n; i += nth) out[i] = v;
+}
+
+static inline dim3 vgrid() { return dim3(ITS_NPART); }
+
+void launch_dot_partials(const double *a, const double *b, int64_t n, double *part, hipStream_t s)
+{ hipLaunchKernelGGL(dot_partials_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, a, b, n, part); }
+void launch_absmax_partials(const double *v, int64_t n, double *part, hipStream_t s)
+{ hipLaunchKernelGGL(absmax_partials_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, v, n, part); }
+void launch_reduce_finalize(const double *part, double *out, int mode, hipStream_t s)
+{ hipLaunchKernelGGL(reduce_finalize_kernel, dim3(1), dim3(ITS_BLOCK), 0, s, part, out, mode); }
+void launch_sqrt_scalar(const double *in, double *out, hipStream_t s)
+{ hipLaunchKernelGGL(sqrt_scalar_kernel, dim3(1), dim3(1), 0, s, in, out); }
+void launch_axpby(double *out, const double *a, const double *b, int64_t n, double sc, hipStream_t s)
+{ hipLaunchKernelGGL(axpby_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, out, a, b, n, sc); }
+void launch_scale(double *out, const double *v, double sc, int64_t n, hipStream_t s)
+{ hipLaunchKernelGGL(scale_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, out, v, sc, n); }
+void launch_copy(double *out, const double *v, int64_t n, hipStream_t s)
+{ (void)hipMemcpyAsync(out, v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s); }
+void launch_fill(double *out, double v, int64_t n, hipStream_t s)
+{ hipLaunchKernelGGL(fill_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, out, v, n); }
+
+// ======================================================================================
+// CG vector updates (methods/cg.hpp:204-230) with the reductions fused in.
+// ======================================================================================
+__global__ __launch_bounds__(ITS_BLOCK) void cg_update_xr_kernel(
+    double *__restrict__ x, double *__restrict__ r, const double *__restrict__ p,
+    const double *__restrict__ q, int64_t n, const double *__restrict__ part_pq, int pq_is_scalar,
+    const double *__restrict__ rr_in, double *__restrict__ sc, double *__restrict__ part_rr)
+{
+    __shared__ double s_red[4];
+    const double pq = pq_is_scalar ? part_pq[0] : sum_partials(part_pq, s_red);
+    const double alpha = rr_in[0] / pq;                        // cg.hpp:162
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    double s0 = 0.0, s1 = 0.0;
+    const int64_t n2 = n / 2;                                  // solver vectors are 256-byte aligned
+    double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *p2 = reinterpret_cast<const double2 *>(p), *q2 = reinterpret_cast<const double2 *>(q);
+    for (int64_t i = tid; i < n2; i += nth) {
+        double2 xv = x2[i], rv = r2[i];
+        const double2 pv = p2[i], qv = q2[i];
+        xv.x = fma(alpha, pv.x, xv.x); xv.y = fma(alpha, pv.y, xv.y);      // cg.hpp:181
+        rv.x = fma(-alpha, qv.x, rv.x); rv.y = fma(-alpha, qv.y, rv.y);    // cg.hpp:182
+        x2[i] = xv; r2[i] = rv;
+        s0 = fma(rv.x, rv.x, s0); s1 = fma(rv.y, rv.y, s1);                // cg.hpp:186
+    }
+    for (int64_t i = 2 * n2 + tid; i < n; i += nth) {
+        x[i] = fma(alpha, p[i], x[i]);
+        const double rv = fma(-alpha, q[i], r[i]);
+        r[i] = rv;
+        s0 = fma(rv, rv, s0);
+    }
+    const double bs = block_sum(s0 + s1, s_red);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = bs;
+        if (blockIdx.x == 0) { sc[SC_PQ] = pq; sc[SC_ALPHA] = alpha; }
+    }
+}
+
+__global__ __launch_bounds__(ITS_BLOCK) void cg_update_p_kernel(
+    double *__restrict__ p, const double *__restrict__ r, int64_t n,
+    const double *__restrict__ part_rr, int rr_is_scalar, const double *__restrict__ rr_old_p,
+    double *__restrict__ rr_new_p, double *__restrict__ sc, double *__restrict__ res_out)
+{
+    __shared__ double s_red[4];
+    const double rr_new = rr_is_scalar ? part_rr[0] : sum_partials(part_rr, s_red);
+    const double rr_old = rr_old_p[0];
+    const double beta = rr_new / rr_old;                       // cg.hpp:188
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    const int64_t n2 = n / 2;
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    for (int64_t i = tid; i < n2; i += nth) {
+        double2 pv = p2[i];
+        const double2 rv = r2[i];
+        pv.x = fma(beta, pv.x, rv.x); pv.y = fma(beta, pv.y, rv.y);        // cg.hpp:202
+        p2[i] = pv;
+    }
+    for (int64_t i = 2 * n2 + tid; i < n; i += nth) p[i] = fma(beta, p[i], r[i]);
+    // rr_new goes to the OTHER rr slot (rr_new_p != rr_old_p): other workgroups may still be
+    // reading rr_old.
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        rr_new_p[0] = rr_new; sc[SC_BETA] = beta;
+        if (res_out) res_out[0] = sqrt(rr_new);                // utility_funcs.hpp:483
+    }
+}
+
+void launch_cg_update_xr(double *x, double *r, const double *p, const double *q, int64_t n,
+                         const double *part_pq, int pq_is_scalar, const double *rr_in, double *sc,
+                         double *part_rr, hipStream_t s)
+{ hipLaunchKernelGGL(cg_update_xr_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, x, r, p, q, n, part_pq, pq_is_scalar, rr_in, sc, part_rr); }
+
+void launch_cg_update_p(double *p, const double *r, int64_t n, const double *part_rr, int rr_is_scalar,
+                        const double *rr_old, double *rr_new, double *sc, double *res_out, hipStream_t s)
+{ hipLaunchKernelGGL(cg_update_p_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, p, r, n, part_rr, rr_is_scalar, rr_old, rr_new, sc, res_out); }
+
+// ======================================================================================
+// GMRES: modified Gram-Schmidt as fused "finish previous axpy + start next dot" steps.
+// ======================================================================================
+__global__ __launch_bounds__(ITS_BLOCK) void mgs_step_kernel(
+    double *__restrict__ w, const double *__restrict__ v_prev, const double *__restrict__ part_prev,
+    int prev_is_scalar, const double *__restrict__ v_next, double *__restrict__ part_next,
+    double *__restrict__ h_out, int64_t n)
+{
+    __shared__ double s_red[4];
+    double h = 0.0;
+    if (v_prev) h = prev_is_scalar ? part_prev[0] : sum_partials(part_prev, s_red);
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    double s0 = 0.0;
+    for (int64_t i = tid; i < n; i += nth) {
+        double wi = w[i];
+        if (v_prev) { wi = fma(-h, v_prev[i], wi); w[i] = wi; }            // gmres.hpp:314
+        s0 = fma(wi, v_next ? v_next[i] : wi, s0);                         // gmres.hpp:286 / :359
+    }
+    const double bs = block_sum(s0, s_red);
+    if (threadIdx.x == 0) {
+        part_next[blockIdx.x] = bs;
+        if (blockIdx.x == 0 && h_out && v_prev) h_out[0] = h;
+    }
+}
+
+__global__ __launch_bounds__(ITS_BLOCK) void mgs_normalize_kernel(
+    double *__restrict__ v_out, const double *__restrict__ w, const double *__restrict__ part_ww,
+    int ww_is_scalar, double *__restrict__ h_out, int64_t n)
+{
+    __shared__ double s_red[4];
+    const double nrm = sqrt(ww_is_scalar ? part_ww[0] : sum_partials(part_ww, s_red));
+    const double inv = 1.0 / nrm;                                          // gmres.hpp:389
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    for (int64_t i = tid; i < n; i += nth) v_out[i] = w[i] * inv;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && h_out) h_out[0] = nrm;
+}
+
+__global__ __launch_bounds__(ITS_BLOCK) void gmres_update_x_kernel(
+    double *__restrict__ x, const double *__restrict__ x0, const double *__restrict__ V, int64_t ldv,
+    const double *__restrict__ y, int m, int64_t n)
+{
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    for (int64_t i = tid; i < n; i += nth) {
+        double t = 0.0;
+        for (int k = 0; k < m; ++k) t = fma(V[(int64_t)k * ldv + i], y[k], t);   // kernels.hpp:511-513
+        x[i] = x0[i] + t;                                                   // gmres.hpp:972
+    }
+}
+
+void launch_mgs_step(double *w, const double *v_prev, const double *part_prev, int prev_is_scalar,
+                     const double *v_next, double *part_next, double *h_out, int64_t n, hipStream_t s)
+{ hipLaunchKernelGGL(mgs_step_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, w, v_prev, part_prev, prev_is_scalar, v_next, part_next, h_out, n); }
+void launch_mgs_normalize(double *v_out, const double *w, const double *part_ww, int ww_is_scalar,
+                          double *h_out, int64_t n, hipStream_t s)
+{ hipLaunchKernelGGL(mgs_normalize_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, v_out, w, part_ww, ww_is_scalar, h_out, n); }
+void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t ldv, const double *y_dev,
+                           int m, int64_t n, hipStream_t s)
+{ hipLaunchKernelGGL(gmres_update_x_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, x, x0, V, ldv, y_dev, m, n); }
+
+// ======================================================================================
+// Triangular sweep, one dependency level (or colour) per launch: each listed row computes
+// x_i = (rhs_i - sum_j L_ij x_j) / D_i with the reference's in-order fused chain
+// (kernels.hpp:460-472).  Rows of one level never read each other.
+// ======================================================================================
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_level_kernel(
+    const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+    const int *__restrict__ rows, int n_level_rows, double *x, const double *__restrict__ rhs,
+    const double *__restrict__ D)
+{
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    for (int64_t k = tid; k < n_level_rows; k += nth) {
+        const int row = rows ? rows[k] : (int)k;
+        double s = 0.0;
+        for (int j = rp[row]; j < rp[row + 1]; ++j) s = fma(val[j], x[col[j]], s);
+        x[row] = (rhs[row] - s) / D[row];
+    }
+}
+
+void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, double *x,
+                        const double *rhs, const double *D, hipStream_t s)
+{
+    int g = (n_level_rows + ITS_BLOCK - 1) / ITS_BLOCK;
+    if (g > ITS_NPART) g = ITS_NPART;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(sweep_level_kernel, dim3(g), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val,
+                       rows, n_level_rows, x, rhs, D);
+}
+
+}  // namespace its

@@ -243,6 +243,7 @@ static void dense_mm(const double *A, const double *B, double *C, int nrA, int n
 }
 
 extern "C" int orc_num_threads(void) { return omp_get_max_threads(); }
+extern "C" void orc_set_threads(int t) { omp_set_num_threads(t > 0 ? t : 1); }
 
 // ===================================================================== L2-L4: solve
 namespace {

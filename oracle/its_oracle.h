@@ -90,6 +90,8 @@ int orc_solve(int n, const int *row_ptr, const int *col, const double *val,
               double *history, double *x_star, orc_result *out);
 
 int orc_num_threads(void);
+/* 1 thread = bit-identical to the compiled reference at OMP_NUM_THREADS=1 */
+void orc_set_threads(int t);
 
 #ifdef __cplusplus
 }

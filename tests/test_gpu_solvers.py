@@ -1,0 +1,126 @@
+"""GPU parity: whole solves through the C ABI (host mirror in iterative_solvers_amd/solver.py)
+against the oracle, which is itself pinned bit-for-bit to the compiled reference.
+
+Bar (BASELINE.json north_star): residual history within 1e-10 relative, iteration count ±1 %.
+Reading used here (SURVEY.md §7 "hard parts"): |r_k^gpu − r_k^cpu| ≤ 1e-10·max(r_k^cpu, 1e-2·‖r_0‖)
+for every recorded trip — 1e-10 relative over the first two decades of convergence and
+1e-12·‖r_0‖ absolute below that (100x tighter than the |Δ|/‖r_0‖ ≤ 1e-10 reading SURVEY.md
+proposes).  Below ≈1e-13·‖r_0‖ neither side has correct digits left: a recomputed residual
+b − A x (Jacobi/GS every trip, GMRES at every restart) carries an absolute error of about
+eps·‖A‖‖x‖, e.g. restarted GMRES(10) on lap2d_16 differs by 5e-7 RELATIVE at ‖r‖ = 1.4e-6,
+which is 6e-14·‖r_0‖.
+
+Iteration counts: with the reference's default TOL=1e-14 the stopping value lies BELOW the
+attainable accuracy (‖r‖/‖r_0‖ ≈ 1e-16), so the last ~10 % of trips are rounding noise: the
+compiled reference itself needs 185 trips at 1 thread and 177 at 32 threads on lap2d_64
+(measured).  The ±1 % bar is therefore asserted with TOL=1e-10 (above the noise floor); the
+TOL=1e-14 runs assert the history bound and a ±15 % count band.  The oracle runs with 1 thread
+(= bit-identical to the compiled reference at OMP_NUM_THREADS=1).
+"""
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from helpers import MATRICES
+from iterative_solvers_amd import capi, solver as S
+
+pytestmark = pytest.mark.gpu
+
+KIND = {"-j": orc.JACOBI, "-gs": orc.GAUSS_SEIDEL, "-cg": orc.CG, "-gm": orc.GMRES}
+
+
+def run_both(name, flag, scale="none", precond="", max_iters=400, restart=100, jacobi_mode=0, tol=1e-10,
+             fmt=capi.FMT_CSR_EXACT):
+    orc.set_threads(1)
+    rp, col, val = MATRICES[name]()
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    # reference preprocessing on the COO (oracle) and in the product host code (numpy)
+    Vo, rs_o = orc.scale_coo(n, rows, col, val, scale)
+    rpo, colo, valo = orc.coo_to_crs(n, rows, col, Vo)
+    bo = 1.0 / (rs_o * rs_o)
+    ref = orc.solve(rpo, colo, valo, bo, bo.copy(), KIND[flag], jacobi_mode=jacobi_mode, precond=orc.PRECOND[precond],
+                    max_iters=max_iters, restart_len=restart, tol=tol)
+    args = S.Args(S.CLI_SOLVER[flag], S.LoopParams(max_iters=max_iters, tol=tol, gmres_restart_len=restart), S.Flags(),
+                  {"": "", "gs": "gauss-seidel"}[precond], scale)
+    sol = S.Solver(args.solver_type, args.preconditioner_type, device=0, spmv_format=fmt, jacobi_mode=jacobi_mode)
+    try:
+        S.preprocessing(args, sol, n, rows.astype(np.int64), col.astype(np.int64), val.copy())
+        S.solve(args, sol)
+        xs = sol.x_star.copy()
+    finally:
+        sol.handle.close()
+    return ref, args, xs
+
+
+def check_history(ref, args, tol_rel=1e-10, count_band=0.01):
+    lp = args.loop_params
+    assert abs(lp.stopping_criteria - ref["stopping"]) <= 1e-13 * abs(ref["stopping"])
+    it_tol = max(1, int(round(count_band * ref["iters"])))
+    assert abs(lp.iter_count - ref["iters"]) <= it_tol, (lp.iter_count, ref["iters"])
+    assert args.flags.convergence_flag == ref["converged"]
+    k = min(lp.residual_count, len(ref["history"]))
+    got = args.normed_residuals[:k]; exp = ref["history"][:k]
+    r0 = ref["r0_two"]
+    bound = tol_rel * np.maximum(exp, 1e-2 * r0)
+    bad = np.nonzero(np.abs(got - exp) > bound)[0]
+    assert bad.size == 0, f"first mismatch at trip {bad[0]}: {got[bad[0]]!r} vs {exp[bad[0]]!r}"
+
+
+@pytest.mark.parametrize("name", ["lap2d_16", "lap2d_64", "lap3d_16", "pl_200"])
+@pytest.mark.parametrize("scale", ["none", "diag", "max"])
+def test_cg(name, scale):
+    ref, args, xs = run_both(name, "-cg", scale, max_iters=600)
+    check_history(ref, args)
+    assert np.max(np.abs(xs - ref["x_star"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["x_star"])))
+
+
+@pytest.mark.parametrize("name", ["lap2d_64", "lap3d_16"])
+def test_cg_reference_default_tol(name):
+    """TOL=1e-14 (config.mk default): below the rounding floor, see module docstring."""
+    ref, args, xs = run_both(name, "-cg", "none", max_iters=600, tol=1e-14)
+    check_history(ref, args, count_band=0.15)
+
+
+@pytest.mark.parametrize("fmt", [capi.FMT_CSR_VECTOR, capi.FMT_SELL])
+def test_cg_reordered_formats(fmt):
+    ref, args, xs = run_both("lap3d_16", "-cg", "none", fmt=fmt)
+    check_history(ref, args)
+
+
+@pytest.mark.parametrize("name,restart", [("lap2d_16", 100), ("lap2d_16", 10), ("cd27_12", 50), ("cd27_12", 10),
+                                           ("lap3d_16", 50), ("pl_200", 10)])
+def test_gmres(name, restart):
+    ref, args, xs = run_both(name, "-gm", "none", restart=restart, max_iters=500)
+    check_history(ref, args)
+    assert np.max(np.abs(xs - ref["x_star"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["x_star"])))
+
+
+@pytest.mark.parametrize("name", ["lap2d_16", "cd27_6"])
+def test_gmres_gs_preconditioned(name):
+    ref, args, xs = run_both(name, "-gm", "diag", precond="gs", restart=10, max_iters=300)
+    check_history(ref, args)
+
+
+@pytest.mark.parametrize("name,scale", [("lap2d_16", "none"), ("lap2d_16", "diag"), ("cd27_6", "diag"), ("pl_200", "diag"), ("pl_5000", "none")])
+def test_gauss_seidel_level_scheduled(name, scale):
+    """Natural-order GS by dependency levels: same arithmetic per row as the serial sweep."""
+    ref, args, xs = run_both(name, "-gs", scale, max_iters=150)
+    check_history(ref, args)
+    assert np.max(np.abs(xs - ref["x_star"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["x_star"])))
+
+
+@pytest.mark.parametrize("name,scale", [("lap2d_16", "diag"), ("lap2d_16", "none"), ("pl_200", "diag"), ("cd27_6", "max")])
+def test_jacobi_shipped_bug_compatible(name, scale):
+    """Bug-compatible with methods/jacobi.hpp:191 (swapped SpMV arguments): stalls or diverges
+    exactly like the shipped binary."""
+    ref, args, xs = run_both(name, "-j", scale, max_iters=120)
+    check_history(ref, args, tol_rel=1e-10)
+
+
+@pytest.mark.parametrize("name", ["lap2d_16", "pl_200", "pl_5000", "cd27_6"])
+def test_jacobi_ref_correct_mode(name):
+    """Correct sweep = jacobi_iteration_ref_cpu (methods/jacobi.hpp:65-93)."""
+    ref, args, xs = run_both(name, "-j", "none", max_iters=200, jacobi_mode=1)
+    check_history(ref, args)
+    assert np.max(np.abs(xs - ref["x_star"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["x_star"])))
