@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the solver hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 256] [--format exact|vector|sell]
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): conjugate gradient, fp64, 3-D 7-point
+Laplacian, 256^3 rows PER GPU (N GPUs: z-slabs of one 256 x 256 x 256N grid — configs[4] at
+N = 8), b = 1, x0 = 1, no scaling.  One "step" = one CG iteration through the reference's loop
+body (Solver::iterate + record_residual_norm + exchange_arrays, solver_harness.hpp:40-116),
+INCLUDING the per-trip 8-byte residual read-back the harness needs for its stopping test.
+The matrix and all vectors are resident in HBM before the timed region starts.
+
+Prints ONE JSON line (rank 0): value = CG iterations/s x (number of 256^3 slabs) — whole-job
+throughput in slab-iterations per second, so weak scaling is value(N) / (N value(1)).
+`roofline` prices the dominant kernel (the CSR SpMV fused with the p.Ap partial sums) against
+the ~8 TB/s HBM peak; `cpu_baseline` times the oracle (CPU restatement of the reference loop,
+arithmetic pinned to the compiled reference) on the box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def spmv_bytes(n, nnz):
+    """Algorithmic bytes of one CSR SpMV: 12 nnz + 4 (n+1) + 8 n (x) + 8 n (y)."""
+    return 12 * nnz + 4 * (n + 1) + 16 * n
+
+
+def cg_iter_bytes(n, nnz):
+    """SpMV + 9 vector passes (x,p->x; r,Ap->r with fused dot; r,p->p) = SpMV + 72 n."""
+    return spmv_bytes(n, nnz) + 72 * n
+
+
+def cpu_baseline(rp, col, val, n, budget_s=15.0):
+    """Oracle CG on the host cores, bounded sample (kind 'port': our restatement of the loop)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py as orc
+    threads = int(os.environ.get("ITS_CPU_THREADS", "0")) or min(orc.num_threads(), os.cpu_count() or 1)
+    orc.set_threads(threads)
+    b = np.ones(n); x0 = np.ones(n)
+    probe = orc.solve(rp, col, val, b, x0, orc.CG, fixed_iters=2, max_iters=2)
+    per_it = max(probe["seconds"] / 2, 1e-6)
+    iters = int(max(3, min(200, budget_s / per_it)))
+    res = orc.solve(rp, col, val, b, x0, orc.CG, fixed_iters=iters, max_iters=iters)
+    return {"value": iters / res["seconds"], "unit": "it/s", "cores": threads, "kind": "port",
+            "sample": f"{iters} CG iterations (reference loop as written: 1 SpMV + 15 vector passes) "
+                      f"on the same {n}-row system, oracle/libits_oracle.so with {threads} OpenMP threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--grid", type=int, default=256, help="grid edge N: N^3 rows per GPU")
+    ap.add_argument("--format", default="exact", choices=["exact", "vector", "sell"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--spmv-reps", type=int, default=50)
+    a = ap.parse_args()
+
+    # NOTE: this process never imports torch — PyTorch's wheel bundles a second ROCm runtime
+    # (7.0) that must not share an address space with the /opt/rocm runtime libits_hip.so uses
+    # (iterative_solvers_amd/rendezvous.py explains).  The launcher may still be
+    # `python -m torch.distributed.run`: only its RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* are read.
+    from iterative_solvers_amd import capi, matgen, solver as S
+    from iterative_solvers_amd.rendezvous import Rendezvous
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and a.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    rdzv = Rendezvous(rank, world)
+    dist = rdzv if world > 1 else None
+    fmt = {"exact": capi.FMT_CSR_EXACT, "vector": capi.FMT_CSR_VECTOR, "sell": capi.FMT_SELL}[a.format]
+    N = a.grid
+
+    t_gen = time.time()
+    sol = S.Solver("conjugate-gradient", device=local_rank, spmv_format=fmt)
+    h = sol.handle
+    if world == 1:
+        rp, col, val = matgen.laplace3d_7pt(N)
+        n = len(rp) - 1
+        nnz = len(col)
+        args = S.Args("conjugate-gradient", S.LoopParams(max_iters=10**9, tol=0.0))
+        S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+    else:
+        from iterative_solvers_amd import distributed as D
+        rp, colg, val = matgen.laplace3d_7pt_slab(N, rank * N, (rank + 1) * N, world * N)
+        n = len(rp) - 1
+        nnz = len(colg)
+        D.init_comm(h, rank, world, rdzv)
+        D.upload_slab(h, world * n, rank * n, rp, colg, val, fmt)
+        diag = np.full(n, 6.0)
+        h.upload_vectors(diag, np.ones(n), np.ones(n))
+        h.init_residual()
+        h.solver_setup(capi.CG)
+    t_gen = time.time() - t_gen
+
+    def barrier():
+        # device-wide sync (hipStreamSynchronize on the only stream that has work) on both
+        # sides of the cross-rank barrier
+        h.synchronize()
+        if dist is not None:
+            dist.barrier()
+        h.synchronize()
+
+    it = 0
+    for _ in range(a.warmup):
+        h.iterate(it); it += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        h.iterate(it); it += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dt = dist.allreduce_max(dt)
+    ms_per_step = dt / a.steps * 1e3
+    its_per_s = a.steps / dt
+
+    # same loop without the per-trip read-back (one sync at the end) — reported beside `value`
+    res = h.iterate_n(it, a.steps); it += a.steps
+    async_ms = h.last_region_ms() / a.steps
+
+    out = None
+    if rank == 0:
+        # dominant kernel: the in-loop SpMV (+ fused p.Ap partials), HIP events on the handle's stream
+        xd = h.to_dev(np.ones(n + 2 * N * N)); yd = h.dev_alloc(8 * n)
+        roof = None
+        spmv_all = {}
+        if world == 1:
+            h.spmv_timed(xd, yd, fmt, reps=5, with_dot=True)
+            k_ms = h.spmv_timed(xd, yd, fmt, reps=a.spmv_reps, with_dot=True)
+            ach = spmv_bytes(n, nnz) / (k_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "kernel": "spmv_stream_kernel<EPI_STORE,DOT>" if fmt == capi.FMT_CSR_EXACT else a.format,
+                    "kernel_ms": k_ms, "algorithmic_bytes": spmv_bytes(n, nnz)}
+            for nm, f in (("exact", capi.FMT_CSR_EXACT), ("vector", capi.FMT_CSR_VECTOR)):
+                h.spmv_timed(xd, yd, f, reps=3)
+                ms = h.spmv_timed(xd, yd, f, reps=a.spmv_reps)
+                spmv_all[nm] = {"ms": ms, "GB/s": spmv_bytes(n, nnz) / (ms * 1e-3) / 1e9}
+        cpu = None
+        if not a.no_cpu and world == 1:
+            cpu = cpu_baseline(rp, col, val, n)
+        out = {
+            "metric": "cg_iters_per_sec", "value": its_per_s * world, "unit": "it/s (256^3-slab iterations)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"CG fp64, 3-D 7-pt Laplacian, {N}^3 rows per GPU (grid {N}x{N}x{N * world}), b=1, x0=1, -scale none",
+                       "rows_per_gpu": n, "nnz_per_gpu": nnz, "spmv_format": a.format,
+                       "parallelism": f"row-block z-slabs x{world}" if world > 1 else "single GPU"},
+            "cg_GBps_algorithmic": cg_iter_bytes(n, nnz) * its_per_s / 1e9,
+            "cg_frac_of_hbm_peak": cg_iter_bytes(n, nnz) * its_per_s / 1e9 / HBM_PEAK_GBS,
+            "async_loop_ms_per_step": async_ms,
+            "last_residual": float(res[-1]),
+            "spmv": spmv_all, "setup_seconds": t_gen,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+    h.close()
+    rdzv.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,8 +106,10 @@ int its_synchronize(its_handle *h);
 /* ---- introspection for bench.py ----------------------------------------------------- */
 /* average duration (ms) of the last its_spmv_timed / its_iterate_n region, measured with HIP
  * events on the handle's own stream */
+/* with_dot != 0 launches the variant the CG loop uses (y = A x fused with the partial sums
+ * of y.x, methods/cg.hpp:128,160) so its duration matches the in-loop kernel. */
 int its_spmv_timed(its_handle *h, int which, const double *x_dev, double *y_dev, int format,
-                   int reps, float *avg_ms);
+                   int with_dot, int reps, float *avg_ms);
 int its_last_region_ms(its_handle *h, float *ms);
 /* plan facts: lanes per row chosen, SELL occupancy (nnz / stored elements), row-block count */
 int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occupancy,

@@ -53,7 +53,7 @@ SIGNATURES = {
     "its_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "its_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "its_synchronize": (C.c_int, [C.c_void_p]),
-    "its_spmv_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "its_spmv_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "its_last_region_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "its_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_int_p, _c_dbl_p, _c_int_p]),
     "its_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -172,9 +172,9 @@ class Handle:
     def spmv_dev(self, x_ptr: int, y_ptr: int, which=MAT_A, fmt=FMT_CSR_EXACT):
         self.check(self.L.its_spmv(self.h, which, C.c_void_p(x_ptr), C.c_void_p(y_ptr), 1, fmt), "its_spmv")
 
-    def spmv_timed(self, x_ptr: int, y_ptr: int, fmt=FMT_CSR_EXACT, reps=20, which=MAT_A) -> float:
+    def spmv_timed(self, x_ptr: int, y_ptr: int, fmt=FMT_CSR_EXACT, reps=20, which=MAT_A, with_dot=False) -> float:
         ms = C.c_float()
-        self.check(self.L.its_spmv_timed(self.h, which, C.c_void_p(x_ptr), C.c_void_p(y_ptr), fmt, reps, C.byref(ms)), "its_spmv_timed")
+        self.check(self.L.its_spmv_timed(self.h, which, C.c_void_p(x_ptr), C.c_void_p(y_ptr), fmt, int(with_dot), reps, C.byref(ms)), "its_spmv_timed")
         return ms.value
 
     def last_region_ms(self) -> float:

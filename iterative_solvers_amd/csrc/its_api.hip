@@ -746,12 +746,13 @@ extern "C" int its_spmv(its_handle *h, int which, const double *x, double *y, in
     return rc;
 }
 
-extern "C" int its_spmv_timed(its_handle *h, int which, const double *x_dev, double *y_dev, int format, int reps, float *avg_ms)
+extern "C" int its_spmv_timed(its_handle *h, int which, const double *x_dev, double *y_dev, int format, int with_dot, int reps, float *avg_ms)
 {
     if (!h || which < 0 || which > 2 || !x_dev || !y_dev || reps < 1 || !avg_ms) return ITS_EINVAL;
     if (!h->have[which]) FAIL(h, ITS_ESTATE, "matrix not uploaded");
     HIPCHK(h, hipSetDevice(h->device));
     SpmvArgs a; a.x = x_dev; a.y = y_dev;
+    if (with_dot) { a.dotv = x_dev; a.part_sum = h->part[3]; }
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     for (int i = 0; i < reps; ++i) { int rc = spmv_dispatch(h, h->mat[which], a, EPI_STORE, format); if (rc) return rc; }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));

@@ -204,3 +204,20 @@ def write_mtx(path: str, row_ptr, col, val, n_cols: int | None = None) -> None:
         f.write(f"{n} {n_cols} {len(col)}\n")
         for r, c, v in zip(rows, col, val):
             f.write(f"{r + 1} {int(c) + 1} {float(v):.17g}\n")
+
+
+def laplace3d_7pt_slab(N: int, z0: int, z1: int, NZ: int):
+    """Rows of planes [z0, z1) of the N×N×NZ 7-point Laplacian with GLOBAL int64 column indices.
+
+    Used by the row-block (z-slab) partition of the multi-GPU path: rank r of G owns planes
+    [r·NZ/G, (r+1)·NZ/G).  Built from a slab with one ghost plane on each interior side; the
+    ghost planes' own rows are dropped, so every kept row equals the global matrix's row.
+    """
+    g0 = max(z0 - 1, 0); g1 = min(z1 + 1, NZ)
+    rp, col, val = laplace3d_7pt(N, nz=g1 - g0)
+    plane = N * N
+    r0 = (z0 - g0) * plane; r1 = r0 + (z1 - z0) * plane
+    a, b = int(rp[r0]), int(rp[r1])
+    row_ptr = (rp[r0:r1 + 1].astype(np.int64) - a).astype(np.int32)
+    col_g = col[a:b].astype(np.int64) + g0 * plane
+    return row_ptr, col_g, val[a:b].copy()
