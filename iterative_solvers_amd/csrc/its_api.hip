@@ -83,7 +83,7 @@ template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nul
 
 static void free_csr(CsrDev &A)
 {
-    dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_row);
+    dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_row); dfree(A.blk_desc);
     dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val);
     A = CsrDev();
 }
@@ -137,14 +137,15 @@ extern "C" int its_destroy(its_handle *h)
 // ---------------------------------------------------------------------------------------
 // host-side plans
 // ---------------------------------------------------------------------------------------
-static void build_stream_plan(int n, const int *rp, std::vector<int> &blk)
+static void build_stream_plan(int n, const int *rp, std::vector<int> &blk, int max_rows = ITS_BLOCK,
+                              int max_nnz = SPMV_NNZ_MAX)
 {
     blk.clear(); blk.push_back(0);
     int rs = 0;
     while (rs < n) {
         int re = rs + 1;                                     // a block always takes one row
         const int64_t a0 = rp[rs];
-        while (re < n && re - rs < ITS_BLOCK && (int64_t)rp[re + 1] - a0 <= SPMV_NNZ_MAX) ++re;
+        while (re < n && re - rs < max_rows && (int64_t)rp[re + 1] - a0 <= max_nnz) ++re;
         blk.push_back(re);
         rs = re;
     }
@@ -224,11 +225,11 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     // validate what the kernels assume: monotone row_ptr, columns inside [0, n_cols)
     for (int i = 0; i < n_rows; ++i) if (row_ptr[i + 1] < row_ptr[i]) FAIL(h, ITS_EINVAL, "row_ptr not monotone");
     for (int64_t k = 0; k < nnz; ++k) if (col[k] < 0 || col[k] >= n_cols) FAIL(h, ITS_EINVAL, "column index out of range");
-    if (dalloc(h, &A.row_ptr, (size_t)n_rows + 1) || dalloc(h, &A.col, (size_t)nnz + 8) || dalloc(h, &A.val, (size_t)nnz + 8))
+    if (dalloc(h, &A.row_ptr, (size_t)n_rows + 1) || dalloc(h, &A.col, (size_t)nnz + CSR_PAD) || dalloc(h, &A.val, (size_t)nnz + CSR_PAD))
         return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.row_ptr, row_ptr, ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemset(A.col + nnz, 0, 8 * sizeof(int)));
-    HIPCHK(h, hipMemset(A.val + nnz, 0, 8 * sizeof(double)));
+    HIPCHK(h, hipMemset(A.col + nnz, 0, CSR_PAD * sizeof(int)));
+    HIPCHK(h, hipMemset(A.val + nnz, 0, CSR_PAD * sizeof(double)));
     if (nnz) {
         HIPCHK(h, hipMemcpy(A.col, col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(A.val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
@@ -238,6 +239,11 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     A.n_blocks = (int)blk.size() - 1;
     if (dalloc(h, &A.blk_row, blk.size())) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.blk_row, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<int4> desc(std::max(A.n_blocks, 1));
+    for (int i = 0; i < A.n_blocks; ++i)
+        desc[i] = make_int4(blk[i], blk[i + 1] - blk[i], row_ptr[blk[i]], row_ptr[blk[i + 1]]);
+    if (dalloc(h, &A.blk_desc, desc.size())) return ITS_EHIP;
+    HIPCHK(h, hipMemcpy(A.blk_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
     A.lanes_per_row = pick_lanes_per_row(n_rows, nnz);
     if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; }
     h->have[which] = true;

@@ -12,7 +12,10 @@ namespace its {
 // SPMV_NNZ_MAX nonzeros (a single longer row forms a block of its own and is walked in
 // several LDS chunks).  blk_row[nb+1] holds the first row of each block.
 // ---------------------------------------------------------------------------------------
-constexpr int SPMV_NNZ_MAX = 1792;      // 256 rows x 7 nnz; 1792*(8+4) B + row ptrs ≈ 22.6 KB LDS
+constexpr int SPMV_NNZ_MAX = 1536;      // (1536+8)*(8+4) B + row ptrs ≈ 19.6 KB LDS per buffer
+// col/val are allocated with this many zero elements after nnz: the stream kernel's prefetch
+// loads are unconditional (2 slices x 1024 entries past an aligned block start)
+constexpr int CSR_PAD = 2048 + 16;
 
 enum SpmvEpilogue {
     EPI_STORE = 0,        // y = A x                                  (kernels.hpp:380-409)
@@ -25,11 +28,12 @@ enum SpmvEpilogue {
 struct CsrDev {
     int n_rows = 0, n_cols = 0;
     int64_t nnz = 0;
-    int *row_ptr = nullptr, *col = nullptr;   // col/val padded by 8 elements for aligned over-read
+    int *row_ptr = nullptr, *col = nullptr;   // col/val padded by CSR_PAD elements
     double *val = nullptr;
     // stream plan
     int n_blocks = 0;
     int *blk_row = nullptr;
+    int4 *blk_desc = nullptr;                 // {first row, rows, first nnz, end nnz} per row block
     // vector-CSR plan
     int lanes_per_row = 0;
     // SELL-64-sigma image
@@ -49,6 +53,7 @@ struct SpmvArgs {
     double *part_max = nullptr;    // ITS_NPART partial max|r| (EPI_RESIDUAL, optional)
     // distributed runs: only rows of this class are processed (0 = all, 1 = interior, 2 = boundary)
     int row_begin = 0, row_end = -1;
+    int map_mode = 0;              // work map of the stream kernel (see spmv_stream2_kernel)
 };
 
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);

@@ -2,6 +2,7 @@
 // All kernels: 256-thread workgroups (4 wavefronts of 64), grid = ITS_NPART workgroups
 // (8 per CU on 256 CUs) walking their share of the work; HBM-bandwidth bound, no MFMA.
 #include "its_kernels.h"
+#include <cstdlib>
 
 namespace its {
 
@@ -101,9 +102,232 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream_kernel(
     }
 }
 
-void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s)
+// --------------------------------------------------------------------------------------
+// v2 of the stream kernel: software-pipelined, one barrier per row block.
+//   * while one lane per row walks row block rb out of LDS buffer `cur`, the col/val/row_ptr
+//     segment of the NEXT row block is in flight into registers; it is committed to the other
+//     LDS buffer at the top of the next trip.
+//   * gfx950 retires vector-memory operations in issue order (s_waitcnt vmcnt(N) = "all but the
+//     N youngest"), so the x gathers of the walk are issued BEFORE the prefetch loads and the
+//     prefetch loads are unconditional (clamped addresses, CSR_PAD slack): the compiler can
+//     then wait for the gathers with a counted vmcnt that leaves the prefetch in flight.
+//   * the walk gathers x in batches of 8 entries (the L2 round trips overlap); the fused
+//     multiply-adds still run strictly in CRS order from 0.0 — bit-exact.
+//   * work map (a.map_mode): 0 = each workgroup owns one contiguous run of row blocks
+//     (XCD-aware slot); 1 = each XCD (blockIdx % 8) owns a contiguous eighth of the row blocks
+//     and its G/8 workgroups interleave over it, so an XCD works inside one compact sliding
+//     window (few open DRAM pages, x window resident in its L2).
+// Row blocks are described by blk_desc[rb] = {first row, rows, first nnz, end nnz}.
+// --------------------------------------------------------------------------------------
+constexpr int S2_CAP = SPMV_NNZ_MAX + 8;
+static_assert(SPMV_NNZ_MAX + 3 <= 2 * 4 * ITS_BLOCK, "staging is written for two slices of 4 entries per lane");
+
+template <int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
+    int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
+    const int *__restrict__ col, const double *__restrict__ val, int n_rows, SpmvArgs a)
 {
-    dim3 g(ITS_NPART), b(ITS_BLOCK);
+    __shared__ __attribute__((aligned(16))) double s_val[2][S2_CAP];
+    __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];
+    __shared__ int s_rp[2][ITS_BLOCK + 4];
+    __shared__ double s_red[4];
+
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    int rb0, rb1, rstep;
+    if (a.map_mode == 0) {
+        const int slot = xcd_slot(blockIdx.x, G);
+        rb0 = (int)(((int64_t)slot * nb) / G);
+        rb1 = (int)(((int64_t)(slot + 1) * nb) / G);
+        rstep = 1;
+    } else {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        const int X0 = (int)(((int64_t)xcd * nb) / 8), X1 = (int)(((int64_t)(xcd + 1) * nb) / 8);
+        rb0 = X0 + jx; rb1 = X1; rstep = G >> 3;
+    }
+    const int niter = rb0 < rb1 ? (rb1 - rb0 + rstep - 1) / rstep : 0;
+    const int rb_last = rb0 + (niter - 1) * rstep;
+
+    double lane_sum = 0.0, lane_max = 0.0;
+
+    // staging registers of the block in flight: named scalars (arrays would go to scratch)
+    int4 rcA, rcB;
+    double2 rvA0, rvA1, rvB0, rvB1;
+    int rrp;
+
+#define S2_ISSUE(d)                                                                       \
+    do {                                                                                  \
+        const int iA_ = ((d).z & ~3) + 4 * t, iB_ = iA_ + 4 * ITS_BLOCK;                  \
+        rcA = *reinterpret_cast<const int4 *>(col + iA_);                                 \
+        rvA0 = *reinterpret_cast<const double2 *>(val + iA_);                             \
+        rvA1 = *reinterpret_cast<const double2 *>(val + iA_ + 2);                         \
+        rcB = *reinterpret_cast<const int4 *>(col + iB_);                                 \
+        rvB0 = *reinterpret_cast<const double2 *>(val + iB_);                             \
+        rvB1 = *reinterpret_cast<const double2 *>(val + iB_ + 2);                         \
+        rrp = rp[min((d).x + t, n_rows)];                                                 \
+    } while (0)
+#define S2_COMMIT(d, buf)                                                                 \
+    do {                                                                                  \
+        const int base_ = (d).z & ~3;                                                     \
+        const int oA_ = 4 * t, oB_ = oA_ + 4 * ITS_BLOCK;                                 \
+        if (base_ + oA_ < (d).w) {                                                        \
+            *reinterpret_cast<int4 *>(&s_col[buf][oA_]) = rcA;                            \
+            *reinterpret_cast<double2 *>(&s_val[buf][oA_]) = rvA0;                        \
+            *reinterpret_cast<double2 *>(&s_val[buf][oA_ + 2]) = rvA1;                    \
+        }                                                                                 \
+        if (base_ + oB_ < (d).w) {                                                        \
+            *reinterpret_cast<int4 *>(&s_col[buf][oB_]) = rcB;                            \
+            *reinterpret_cast<double2 *>(&s_val[buf][oB_]) = rvB0;                        \
+            *reinterpret_cast<double2 *>(&s_val[buf][oB_ + 2]) = rvB1;                    \
+        }                                                                                 \
+        if (t < (d).y) s_rp[buf][t] = rrp;                                                \
+        if (t == 0) s_rp[buf][(d).y] = (d).w;                                             \
+    } while (0)
+#define S2_BATCH_LOAD(j)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                       \
+        const int jj_ = ((j) + u < j1) ? (j) + u : min((j), S2_CAP - 1);                  \
+        c[u] = s_col[cur][jj_]; v[u] = s_val[cur][jj_];                                   \
+    }                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
+#define S2_BATCH_FMA(j)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                       \
+        if ((j) + u < j1) {                                                               \
+            if (EPI == EPI_JACOBI_REF && c[u] == row) diag = v[u];                        \
+            else acc = fma(v[u], xv[u], acc);                                             \
+        }                                                                                 \
+    }
+
+    int cur = 0;
+    int4 d = make_int4(0, 0, 0, 0), dn = d;
+    if (niter > 0) {
+        d = blk_desc[rb0];
+        dn = blk_desc[min(rb0 + rstep, rb_last)];
+        S2_ISSUE(d);
+    }
+    for (int it = 0; it < niter; ++it) {
+        const int rb = rb0 + it * rstep;
+        const int4 dnn = blk_desc[min(rb + 2 * rstep, rb_last)];
+        const int rs = d.x, nr = d.y;
+        const int row = rs + t;
+        double acc = 0.0, diag = 0.0;
+        const bool lng = d.w - d.z > SPMV_NNZ_MAX;
+        if (!lng) S2_COMMIT(d, cur);
+        __syncthreads();
+        int j0 = 0, j1 = 0;
+        if (!lng && t < nr) {
+            const int base = d.z & ~3;
+            j0 = s_rp[cur][t] - base; j1 = s_rp[cur][t + 1] - base;
+        }
+        int c[8]; double v[8], xv[8];
+        // first batch of the walk: LDS reads and x gathers go out, THEN the prefetch of the
+        // next row block, THEN the arithmetic (waits for the gathers only)
+        S2_BATCH_LOAD(j0)
+        __builtin_amdgcn_sched_barrier(0);
+        S2_ISSUE(dn);
+        __builtin_amdgcn_sched_barrier(0);
+        S2_BATCH_FMA(j0)
+        for (int j = j0 + 8; j < j1; j += 8) {
+            S2_BATCH_LOAD(j)
+            S2_BATCH_FMA(j)
+        }
+        if (lng) {
+            // a single row longer than the LDS capacity: stream it through buffer `cur` in
+            // chunks; lane 0 keeps the in-order chain.  (Rare: power-law tails.)
+            for (int c0 = d.z; c0 < d.w; c0 += SPMV_NNZ_MAX) {
+                const int c1 = min(d.w, c0 + SPMV_NNZ_MAX);
+                const int base = c0 & ~3;
+                __syncthreads();
+                for (int i = base + 4 * t; i < c1; i += 4 * ITS_BLOCK) {
+                    const int o = i - base;
+                    *reinterpret_cast<int4 *>(&s_col[cur][o]) = *reinterpret_cast<const int4 *>(col + i);
+                    *reinterpret_cast<double2 *>(&s_val[cur][o]) = *reinterpret_cast<const double2 *>(val + i);
+                    *reinterpret_cast<double2 *>(&s_val[cur][o + 2]) = *reinterpret_cast<const double2 *>(val + i + 2);
+                }
+                __syncthreads();
+                if (t == 0) {
+                    for (int j = c0 - base; j < c1 - base; ++j) {
+                        const int cc = s_col[cur][j];
+                        const double vv = s_val[cur][j];
+                        if (EPI == EPI_JACOBI_REF && cc == row) diag = vv;
+                        else acc = fma(vv, a.x[cc], acc);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (t < nr) {
+            if (EPI == EPI_STORE) {
+                a.y[row] = acc;
+                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
+            } else if (EPI == EPI_RESIDUAL) {
+                const double r = a.b[row] - acc;
+                a.y[row] = r;
+                lane_sum = fma(r, r, lane_sum);
+                lane_max = fmax(lane_max, fabs(r));
+            } else if (EPI == EPI_JACOBI_SHIPPED) {
+                const double dd = a.D[row];
+                const double adj = fma(-dd, acc, a.x[row]);
+                a.y[row] = (a.b[row] - adj) / dd;
+            } else if (EPI == EPI_JACOBI_REF) {
+                a.y[row] = (a.b[row] - acc) / diag;
+            } else if (EPI == EPI_GS_RHS) {
+                a.y[row] = fma(-1.0, acc, a.b[row]);
+            }
+        }
+        cur ^= 1;
+        d = dn; dn = dnn;
+    }
+#undef S2_ISSUE
+#undef S2_COMMIT
+#undef S2_BATCH_LOAD
+#undef S2_BATCH_FMA
+    if (DOT || EPI == EPI_RESIDUAL) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) {
+            a.part_sum[blockIdx.x] = bs;
+            for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
+        }
+        if (EPI == EPI_RESIDUAL && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) {
+                a.part_max[blockIdx.x] = bm;
+                for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_max[z] = 0.0;
+            }
+        }
+    }
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
+{
+    static const int variant = env_int("ITS_SPMV_VARIANT", 2);
+    dim3 b(ITS_BLOCK);
+    if (variant == 2) {
+        static int g2v = env_int("ITS_SPMV_GRID", 1024);
+        static const int mm = env_int("ITS_SPMV_MAP", 1);
+        if (g2v < 8 || g2v > ITS_NPART || (g2v & 7)) g2v = 1024;
+        dim3 g2(g2v);
+        SpmvArgs a = a_in;
+        a.map_mode = mm;
+#define ITS_LAUNCH2(E, D) \
+    hipLaunchKernelGGL((spmv_stream2_kernel<E, D>), g2, b, 0, s, A.n_blocks, A.blk_desc, A.row_ptr, A.col, A.val, A.n_rows, a)
+        switch (epi) {
+        case EPI_STORE: if (a.dotv) ITS_LAUNCH2(EPI_STORE, true); else ITS_LAUNCH2(EPI_STORE, false); break;
+        case EPI_RESIDUAL: ITS_LAUNCH2(EPI_RESIDUAL, false); break;
+        case EPI_JACOBI_SHIPPED: ITS_LAUNCH2(EPI_JACOBI_SHIPPED, false); break;
+        case EPI_JACOBI_REF: ITS_LAUNCH2(EPI_JACOBI_REF, false); break;
+        case EPI_GS_RHS: ITS_LAUNCH2(EPI_GS_RHS, false); break;
+        }
+#undef ITS_LAUNCH2
+        return;
+    }
+    const SpmvArgs &a = a_in;
+    dim3 g(ITS_NPART);
 #define ITS_LAUNCH(E, D) \
     hipLaunchKernelGGL((spmv_stream_kernel<E, D>), g, b, 0, s, A.n_blocks, A.blk_row, A.row_ptr, A.col, A.val, a)
     switch (epi) {

@@ -10,6 +10,15 @@ b − A x (Jacobi/GS every trip, GMRES at every restart) carries an absolute err
 eps·‖A‖‖x‖, e.g. restarted GMRES(10) on lap2d_16 differs by 5e-7 RELATIVE at ‖r‖ = 1.4e-6,
 which is 6e-14·‖r_0‖.
 
+Ill-conditioned histories: some runs amplify rounding noise by many orders (restarted GMRES(10)
+on lap2d_16: the reference restatement ITSELF moves by 3-4 % at trip ~100 when only its OpenMP
+thread count, i.e. the order of the dot-product reduction, changes from 1 to 2/3/4 — measured).
+There a fixed 1e-10 bound tests the noise, not the implementation.  check_history therefore
+widens the bound at trip k to 10x the largest oracle-vs-oracle deviation seen up to trip k+8
+(oracle at 1 thread vs 2..6 threads; the multi-thread combine order is itself not
+deterministic, hence the margin): the GPU may deviate from the reference no more than the
+reference deviates from itself under a reduction-order change.
+
 Iteration counts: with the reference's default TOL=1e-14 the stopping value lies BELOW the
 attainable accuracy (‖r‖/‖r_0‖ ≈ 1e-16), so the last ~10 % of trips are rounding noise: the
 compiled reference itself needs 185 trips at 1 thread and 177 at 32 threads on lap2d_64
@@ -39,8 +48,18 @@ def run_both(name, flag, scale="none", precond="", max_iters=400, restart=100, j
     Vo, rs_o = orc.scale_coo(n, rows, col, val, scale)
     rpo, colo, valo = orc.coo_to_crs(n, rows, col, Vo)
     bo = 1.0 / (rs_o * rs_o)
-    ref = orc.solve(rpo, colo, valo, bo, bo.copy(), KIND[flag], jacobi_mode=jacobi_mode, precond=orc.PRECOND[precond],
-                    max_iters=max_iters, restart_len=restart, tol=tol)
+    kw = dict(jacobi_mode=jacobi_mode, precond=orc.PRECOND[precond], max_iters=max_iters, restart_len=restart, tol=tol)
+    ref = orc.solve(rpo, colo, valo, bo, bo.copy(), KIND[flag], **kw)
+    # the reference's own sensitivity to reduction order (see module docstring)
+    noise = np.zeros(len(ref["history"]))
+    for t in (2, 3, 4, 5, 6):
+        orc.set_threads(t)
+        alt = orc.solve(rpo, colo, valo, bo, bo.copy(), KIND[flag], **kw)["history"]
+        k = min(len(alt), len(noise))
+        noise[:k] = np.maximum(noise[:k], np.abs(alt[:k] - ref["history"][:k]))
+    orc.set_threads(1)
+    env = np.maximum.accumulate(noise)
+    ref["noise"] = np.concatenate([env[8:], np.full(min(8, len(env)), env[-1] if len(env) else 0.0)])
     args = S.Args(S.CLI_SOLVER[flag], S.LoopParams(max_iters=max_iters, tol=tol, gmres_restart_len=restart), S.Flags(),
                   {"": "", "gs": "gauss-seidel"}[precond], scale)
     sol = S.Solver(args.solver_type, args.preconditioner_type, device=0, spmv_format=fmt, jacobi_mode=jacobi_mode)
@@ -62,7 +81,7 @@ def check_history(ref, args, tol_rel=1e-10, count_band=0.01):
     k = min(lp.residual_count, len(ref["history"]))
     got = args.normed_residuals[:k]; exp = ref["history"][:k]
     r0 = ref["r0_two"]
-    bound = tol_rel * np.maximum(exp, 1e-2 * r0)
+    bound = np.maximum(tol_rel * np.maximum(exp, 1e-2 * r0), 10.0 * ref["noise"][:k])
     bad = np.nonzero(np.abs(got - exp) > bound)[0]
     assert bad.size == 0, f"first mismatch at trip {bad[0]}: {got[bad[0]]!r} vs {exp[bad[0]]!r}"
 
