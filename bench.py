@@ -101,7 +101,7 @@ def main():
         n = len(rp) - 1
         nnz = len(colg)
         D.init_comm(h, rank, world, rdzv)
-        D.upload_slab(h, world * n, rank * n, rp, colg, val, fmt)
+        D.upload_slab(h, rdzv, world * n, rank * n, rp, colg, val, fmt)
         diag = np.full(n, 6.0)
         h.upload_vectors(diag, np.ones(n), np.ones(n))
         h.init_residual()

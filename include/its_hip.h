@@ -115,16 +115,34 @@ int its_last_region_ms(its_handle *h, float *ms);
 int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occupancy,
                   int *n_row_blocks);
 
-/* ---- multi-GPU (no counterpart in the reference, which is single-process) -- */
-/* One process per GPU.  The caller (bench.py, via torch.distributed/gloo) obtains the 128-byte
- * RCCL unique id from rank 0 with its_comm_unique_id and hands it to every rank. */
+/* ---- multi-GPU (no counterpart in the reference, which is single-process:
+ * "TODO: MPI preprocessing will go here", main.cpp:94) ----------------------------------------
+ * One process per GPU, contiguous row blocks.  Order of calls on every rank:
+ *   its_comm_init (or its_comm_init_host) -> its_upload_crs(ITS_MAT_A, n_rows = owned rows,
+ *   n_cols = owned + halo columns, local column indices) -> its_dist_setup -> its_upload_vectors
+ *   -> its_init_residual -> its_solver_setup -> its_iterate ...
+ * Every SpMV of the solver loops then packs/exchanges the halo entries of its input vector
+ * (overlapped with the interior rows) and every dot/norm is all-reduced, all on device streams. */
+/* rank 0 makes an id (128 bytes, RCCL ncclUniqueId); the caller's control plane hands TWO ids
+ * (halo communicator, reduction communicator) to every rank */
 int its_comm_unique_id(void *id128);
-int its_comm_init(its_handle *h, int rank, int world, const void *id128);
-/* Row-block partition of a GLOBAL n_global-row matrix: this rank owns rows
- * [row_begin, row_begin + n_rows); col[] holds GLOBAL column indices.  The library renumbers
- * columns to owned + halo, builds send/recv lists and splits interior/boundary rows. */
-int its_upload_crs_dist(its_handle *h, int64_t n_global, int64_t row_begin, int n_rows, int64_t nnz,
-                        const int *row_ptr, const int64_t *col_global, const double *val, int format);
+int its_comm_init(its_handle *h, int rank, int world, const void *ids256);
+/* Test transport: halo data and scalars are staged through the host and exchanged by the
+ * caller's callbacks (return 0 on success), so several ranks can share one GPU.
+ *   exchange : send[send_off[k]..send_off[k+1]) goes to rank nbr[k];
+ *              recv[recv_off[k]..recv_off[k+1]) must be filled with what nbr[k] sent to us.
+ *   allreduce: vals[0..count) replaced by the sum (op 0) or max (op 1) over all ranks. */
+typedef int (*its_exchange_cb)(void *user, const double *send, const int *send_off, double *recv,
+                               const int *recv_off, const int *nbr, int n_nbr);
+typedef int (*its_allreduce_cb)(void *user, double *vals, int count, int op);
+int its_comm_init_host(its_handle *h, int rank, int world, its_exchange_cb exchange,
+                       its_allreduce_cb allreduce, void *user);
+/* Exchange plan for the uploaded local matrix: n_nbr neighbour ranks (ascending);
+ * send_idx[send_off[k]..send_off[k+1]) = owned rows whose x entries neighbour k needs, in the
+ * order of that neighbour's halo; halo columns n_rows + [recv_off[k], recv_off[k+1]) come from
+ * neighbour k.  Splits the row blocks into interior / boundary for the overlap. */
+int its_dist_setup(its_handle *h, int n_nbr, const int *nbr, const int *send_off,
+                   const int *send_idx, const int *recv_off);
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,7 @@
 // its_api.hip — the extern "C" boundary of libits_hip.so (declared in include/its_hip.h).
 // Host-side state machine that mirrors Solver<VT> (reference solver.hpp) with every vector
 // resident in HBM; the only per-trip host traffic is one 8-byte scalar (GMRES: one H column).
-#include "../../include/its_hip.h"
-#include "its_kernels.h"
+#include "its_handle.h"
 
 #include <algorithm>
 #include <cmath>
@@ -12,74 +11,6 @@
 #include <numeric>
 #include <string>
 #include <vector>
-
-using namespace its;
-
-// ---------------------------------------------------------------------------------------
-struct DistPlan;   // its_dist.hip (multi-GPU); opaque here
-
-struct its_handle {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float last_region_ms = 0.f;
-    std::string err;
-
-    CsrDev mat[3];
-    bool have[3] = {false, false, false};
-    int fmt = ITS_FMT_CSR_EXACT;          // format used by the solver loops for A
-
-    int n = 0;                            // owned rows
-    int n_ext = 0;                        // owned + halo (== n on one GPU)
-    // Solver<VT> vectors (solver.hpp:23-34).  x_a/x_b ping-pong as x_old/x_new.
-    double *D = nullptr, *b = nullptr, *r = nullptr, *tmp = nullptr;
-    double *x_a = nullptr, *x_b = nullptr, *x = nullptr;   // x: GS / GMRES iterate
-    // cgArgs (cg.hpp:16-38): p and q=A p; r is shared
-    double *p = nullptr;
-    // gmresArgs (gmres.hpp:16-42)
-    double *V = nullptr, *hcol_dev = nullptr, *y_dev = nullptr;
-    int m = 0, restart_count = 0;
-    double beta = 0.0;
-    std::vector<double> Rm, g, cs, sn, hcol;   // host: R (col-major (m+1) x m), g, Givens c/s
-    // reductions / scalars
-    double *part[4] = {nullptr, nullptr, nullptr, nullptr};
-    double *sc = nullptr;                 // SC_COUNT device scalars
-    double *res_dev = nullptr;            // per-trip residuals for its_iterate_n
-    int res_cap = 0;
-    double *pinned = nullptr;             // small pinned host buffer
-    int rr_slot = 0;
-
-    int solver = -1, precond = 0, jacobi_mode = 0, gs_order = 0;
-    bool setup_done = false, residual_done = false;
-    double last_residual = 0.0;
-    // triangular sweep schedule (levels of L; colours when the matrix was colour-permuted)
-    std::vector<int> level_ptr;           // host offsets into level_rows
-    int *level_rows = nullptr;            // device
-    int n_levels = 0;
-    // multicolour permutation (gs_order == ITS_GS_MULTICOLOR): new index -> old index
-    std::vector<int> mc_perm, mc_iperm;
-
-    DistPlan *dist = nullptr;
-};
-
-#define HIPCHK(h, call)                                                                     \
-    do {                                                                                    \
-        hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess) {                                                             \
-            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
-            return ITS_EHIP;                                                                \
-        }                                                                                   \
-    } while (0)
-#define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
-
-template <class T> static int dalloc(its_handle *h, T **p, size_t count)
-{
-    void *q = nullptr;
-    HIPCHK(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T) + 256));
-    *p = (T *)q;
-    return ITS_OK;
-}
-template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
 static void free_csr(CsrDev &A)
 {
@@ -275,6 +206,14 @@ extern "C" int its_plan_info(its_handle *h, int which, int format, int *lanes_pe
 // ---------------------------------------------------------------------------------------
 static int spmv_dispatch(its_handle *h, const CsrDev &A, const SpmvArgs &a, int epi, int format)
 {
+    // the stream kernel gathers x[0] for idle lanes: x must have at least one element
+    if (A.n_cols < 1 || A.n_rows < 1) {
+        if (A.n_rows > 0 && epi == EPI_STORE) HIPCHK(h, hipMemsetAsync(a.y, 0, (size_t)A.n_rows * sizeof(double), h->stream));
+        else if (A.n_rows > 0) FAIL(h, ITS_EUNSUPPORTED, "matrix without columns");
+        if (a.part_sum) HIPCHK(h, hipMemsetAsync(a.part_sum, 0, ITS_NPART * sizeof(double), h->stream));
+        if (a.part_max) HIPCHK(h, hipMemsetAsync(a.part_max, 0, ITS_NPART * sizeof(double), h->stream));
+        return ITS_OK;
+    }
     if (epi >= EPI_JACOBI_SHIPPED || format == ITS_FMT_CSR_EXACT) launch_spmv_exact(A, a, epi, h->stream);
     else if (format == ITS_FMT_CSR_VECTOR) launch_spmv_vector(A, a, epi, h->stream);
     else if (format == ITS_FMT_SELL) {

@@ -1,0 +1,78 @@
+// its_handle.h — the library's per-GPU state (opaque `its_handle` of include/its_hip.h), shared by
+// its_api.hip (single-GPU state machine) and its_dist.hip (multi-GPU layer).
+#pragma once
+#include "../../include/its_hip.h"
+#include "its_kernels.h"
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+using namespace its;
+
+// ---------------------------------------------------------------------------------------
+struct DistPlan;   // its_dist.hip (multi-GPU); opaque here
+
+struct its_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_region_ms = 0.f;
+    std::string err;
+
+    CsrDev mat[3];
+    bool have[3] = {false, false, false};
+    int fmt = ITS_FMT_CSR_EXACT;          // format used by the solver loops for A
+
+    int n = 0;                            // owned rows
+    int n_ext = 0;                        // owned + halo (== n on one GPU)
+    // Solver<VT> vectors (solver.hpp:23-34).  x_a/x_b ping-pong as x_old/x_new.
+    double *D = nullptr, *b = nullptr, *r = nullptr, *tmp = nullptr;
+    double *x_a = nullptr, *x_b = nullptr, *x = nullptr;   // x: GS / GMRES iterate
+    // cgArgs (cg.hpp:16-38): p and q=A p; r is shared
+    double *p = nullptr;
+    // gmresArgs (gmres.hpp:16-42)
+    double *V = nullptr, *hcol_dev = nullptr, *y_dev = nullptr;
+    int m = 0, restart_count = 0;
+    double beta = 0.0;
+    std::vector<double> Rm, g, cs, sn, hcol;   // host: R (col-major (m+1) x m), g, Givens c/s
+    // reductions / scalars
+    double *part[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *sc = nullptr;                 // SC_COUNT device scalars
+    double *res_dev = nullptr;            // per-trip residuals for its_iterate_n
+    int res_cap = 0;
+    double *pinned = nullptr;             // small pinned host buffer
+    int rr_slot = 0;
+
+    int solver = -1, precond = 0, jacobi_mode = 0, gs_order = 0;
+    bool setup_done = false, residual_done = false;
+    double last_residual = 0.0;
+    // triangular sweep schedule (levels of L; colours when the matrix was colour-permuted)
+    std::vector<int> level_ptr;           // host offsets into level_rows
+    int *level_rows = nullptr;            // device
+    int n_levels = 0;
+    // multicolour permutation (gs_order == ITS_GS_MULTICOLOR): new index -> old index
+    std::vector<int> mc_perm, mc_iperm;
+
+    DistPlan *dist = nullptr;
+};
+
+#define HIPCHK(h, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return ITS_EHIP;                                                                \
+        }                                                                                   \
+    } while (0)
+#define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
+
+template <class T> static inline int dalloc(its_handle *h, T **p, size_t count)
+{
+    void *q = nullptr;
+    HIPCHK(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T) + 256));
+    *p = (T *)q;
+    return ITS_OK;
+}
+template <class T> static inline void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+

@@ -53,10 +53,15 @@ struct SpmvArgs {
     double *part_max = nullptr;    // ITS_NPART partial max|r| (EPI_RESIDUAL, optional)
     // distributed runs: only rows of this class are processed (0 = all, 1 = interior, 2 = boundary)
     int row_begin = 0, row_end = -1;
+    int part_accum = 0;            // add this launch's partial to part_sum/part_max instead of overwriting
     int map_mode = 0;              // work map of the stream kernel (see spmv_stream2_kernel)
 };
 
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
+// same kernel over an explicit list of row-block descriptors (interior / boundary split of the
+// multi-GPU path); accumulate != 0 adds to the partials an earlier launch left
+void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const SpmvArgs &a, int epilogue,
+                            int accumulate, hipStream_t s);
 void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 

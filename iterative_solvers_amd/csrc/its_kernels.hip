@@ -185,8 +185,11 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
     } while (0)
 #define S2_BATCH_LOAD(j)                                                                  \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                       \
-        const int jj_ = ((j) + u < j1) ? (j) + u : min((j), S2_CAP - 1);                  \
-        c[u] = s_col[cur][jj_]; v[u] = s_val[cur][jj_];                                   \
+        const bool ok_ = (j) + u < j1;                                                    \
+        const int jj_ = ok_ ? (j) + u : 0;                                                \
+        const int cc_ = s_col[cur][jj_];                                                  \
+        c[u] = ok_ ? cc_ : 0;   /* LDS beyond the block's entries is stale: never gather through it */ \
+        v[u] = s_val[cur][jj_];                                                           \
     }                                                                                     \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
 #define S2_BATCH_FMA(j)                                                                   \
@@ -222,6 +225,13 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         // first batch of the walk: LDS reads and x gathers go out, THEN the prefetch of the
         // next row block, THEN the arithmetic (waits for the gathers only)
         S2_BATCH_LOAD(j0)
+        // operands of the epilogue are fetched with the gathers, not after the prefetch (a load
+        // issued after it could only be waited for together with the whole prefetch)
+        const int rowc = min(row, n_rows - 1);
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+        if (EPI == EPI_STORE) { if (DOT) e0 = a.dotv[rowc]; }
+        else if (EPI == EPI_JACOBI_SHIPPED) { e0 = a.D[rowc]; e1 = a.b[rowc]; e2 = a.x[rowc]; }
+        else e0 = a.b[rowc];
         __builtin_amdgcn_sched_barrier(0);
         S2_ISSUE(dn);
         __builtin_amdgcn_sched_barrier(0);
@@ -258,20 +268,19 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         if (t < nr) {
             if (EPI == EPI_STORE) {
                 a.y[row] = acc;
-                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
+                if (DOT) lane_sum = fma(acc, e0, lane_sum);
             } else if (EPI == EPI_RESIDUAL) {
-                const double r = a.b[row] - acc;
+                const double r = e0 - acc;
                 a.y[row] = r;
                 lane_sum = fma(r, r, lane_sum);
                 lane_max = fmax(lane_max, fabs(r));
             } else if (EPI == EPI_JACOBI_SHIPPED) {
-                const double dd = a.D[row];
-                const double adj = fma(-dd, acc, a.x[row]);
-                a.y[row] = (a.b[row] - adj) / dd;
+                const double adj = fma(-e0, acc, e2);
+                a.y[row] = (e1 - adj) / e0;
             } else if (EPI == EPI_JACOBI_REF) {
-                a.y[row] = (a.b[row] - acc) / diag;
+                a.y[row] = (e0 - acc) / diag;
             } else if (EPI == EPI_GS_RHS) {
-                a.y[row] = fma(-1.0, acc, a.b[row]);
+                a.y[row] = fma(-1.0, acc, e0);
             }
         }
         cur ^= 1;
@@ -284,14 +293,20 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
     if (DOT || EPI == EPI_RESIDUAL) {
         const double bs = block_sum(lane_sum, s_red);
         if (t == 0 && a.part_sum) {
-            a.part_sum[blockIdx.x] = bs;
-            for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
+            if (a.part_accum) a.part_sum[blockIdx.x] += bs;
+            else {
+                a.part_sum[blockIdx.x] = bs;
+                for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
+            }
         }
         if (EPI == EPI_RESIDUAL && a.part_max) {
             const double bm = block_max(lane_max, s_red);
             if (t == 0) {
-                a.part_max[blockIdx.x] = bm;
-                for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_max[z] = 0.0;
+                if (a.part_accum) a.part_max[blockIdx.x] = fmax(a.part_max[blockIdx.x], bm);
+                else {
+                    a.part_max[blockIdx.x] = bm;
+                    for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_max[z] = 0.0;
+                }
             }
         }
     }
@@ -303,29 +318,33 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
+void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const SpmvArgs &a_in, int epi,
+                            int accumulate, hipStream_t s)
+{
+    static int g2v = env_int("ITS_SPMV_GRID", 1024);
+    static const int mm = env_int("ITS_SPMV_MAP", 1);
+    if (g2v < 8 || g2v > ITS_NPART || (g2v & 7)) g2v = 1024;
+    dim3 g2(g2v), b(ITS_BLOCK);
+    SpmvArgs a = a_in;
+    a.map_mode = mm;
+    a.part_accum = accumulate;
+#define ITS_LAUNCH2(E, D) \
+    hipLaunchKernelGGL((spmv_stream2_kernel<E, D>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
+    switch (epi) {
+    case EPI_STORE: if (a.dotv) ITS_LAUNCH2(EPI_STORE, true); else ITS_LAUNCH2(EPI_STORE, false); break;
+    case EPI_RESIDUAL: ITS_LAUNCH2(EPI_RESIDUAL, false); break;
+    case EPI_JACOBI_SHIPPED: ITS_LAUNCH2(EPI_JACOBI_SHIPPED, false); break;
+    case EPI_JACOBI_REF: ITS_LAUNCH2(EPI_JACOBI_REF, false); break;
+    case EPI_GS_RHS: ITS_LAUNCH2(EPI_GS_RHS, false); break;
+    }
+#undef ITS_LAUNCH2
+}
+
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
 {
     static const int variant = env_int("ITS_SPMV_VARIANT", 2);
     dim3 b(ITS_BLOCK);
-    if (variant == 2) {
-        static int g2v = env_int("ITS_SPMV_GRID", 1024);
-        static const int mm = env_int("ITS_SPMV_MAP", 1);
-        if (g2v < 8 || g2v > ITS_NPART || (g2v & 7)) g2v = 1024;
-        dim3 g2(g2v);
-        SpmvArgs a = a_in;
-        a.map_mode = mm;
-#define ITS_LAUNCH2(E, D) \
-    hipLaunchKernelGGL((spmv_stream2_kernel<E, D>), g2, b, 0, s, A.n_blocks, A.blk_desc, A.row_ptr, A.col, A.val, A.n_rows, a)
-        switch (epi) {
-        case EPI_STORE: if (a.dotv) ITS_LAUNCH2(EPI_STORE, true); else ITS_LAUNCH2(EPI_STORE, false); break;
-        case EPI_RESIDUAL: ITS_LAUNCH2(EPI_RESIDUAL, false); break;
-        case EPI_JACOBI_SHIPPED: ITS_LAUNCH2(EPI_JACOBI_SHIPPED, false); break;
-        case EPI_JACOBI_REF: ITS_LAUNCH2(EPI_JACOBI_REF, false); break;
-        case EPI_GS_RHS: ITS_LAUNCH2(EPI_GS_RHS, false); break;
-        }
-#undef ITS_LAUNCH2
-        return;
-    }
+    if (variant == 2) { launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s); return; }
     const SpmvArgs &a = a_in;
     dim3 g(ITS_NPART);
 #define ITS_LAUNCH(E, D) \

@@ -1,0 +1,139 @@
+"""Row-block partition of the solver hot path over N GPUs (the reference is a
+single process — "TODO: MPI preprocessing will go here", main.cpp:94 — so this layer is new).
+
+Host-side planning only (numpy, runs once):
+
+* ``plan_partition``   local column renumbering (owned ``[0, n_loc)`` + halo ``[n_loc, n_loc+h)``),
+                       per-neighbour receive ranges of the halo and send index lists;
+* ``upload_slab``      hands the local CRS + exchange plan to ``libits_hip.so``;
+* ``init_comm``        distributes the RCCL unique ids over the control plane.
+
+All per-iteration traffic (halo x-entries, dot/norm all-reduces) moves over RCCL/xGMI inside the
+library.  ``comm`` is any object with ``rank``, ``world`` and ``allgather_bytes(b) -> list[bytes]``
+(``Rendezvous`` in production, a gloo adapter in the CPU tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class PartitionPlan:
+    rank: int
+    world: int
+    n_global: int
+    row_begin: int
+    n_loc: int
+    n_halo: int
+    col_local: np.ndarray          # int32 local column of every nonzero
+    halo_global: np.ndarray        # int64 global ids of the halo columns, ascending
+    nbr: np.ndarray                # int32 neighbour ranks, ascending
+    recv_off: np.ndarray           # int32 [n_nbr+1] offsets into the halo region, per neighbour
+    send_off: np.ndarray           # int32 [n_nbr+1] offsets into send_idx, per neighbour
+    send_idx: np.ndarray           # int32 local row indices to pack, grouped by neighbour
+
+
+def _allgather_arrays(comm, arr: np.ndarray, dtype) -> list[np.ndarray]:
+    blobs = comm.allgather_bytes(np.ascontiguousarray(arr, dtype=dtype).tobytes())
+    return [np.frombuffer(b, dtype=dtype) for b in blobs]
+
+
+def plan_partition(comm, n_global: int, row_begin: int, n_loc: int, col_global: np.ndarray) -> PartitionPlan:
+    """Collective: every rank calls it with its own contiguous row block [row_begin, row_begin+n_loc)."""
+    rank, world = comm.rank, comm.world
+    begins = np.concatenate(_allgather_arrays(comm, np.array([row_begin, n_loc]), np.int64)).reshape(world, 2)
+    starts = begins[:, 0]
+    ends = begins[:, 0] + begins[:, 1]
+    order = np.argsort(starts)
+    if np.any(starts[order][1:] != ends[order][:-1]) or starts[order][0] != 0 or ends[order][-1] != n_global:
+        raise ValueError("row blocks must tile [0, n_global) without gaps or overlap")
+    col_global = np.asarray(col_global, dtype=np.int64)
+    if col_global.size and (col_global.min() < 0 or col_global.max() >= n_global):
+        raise ValueError("global column index out of range")
+    owned = (col_global >= row_begin) & (col_global < row_begin + n_loc)
+    halo_global = np.unique(col_global[~owned])                      # ascending => grouped by owner
+    n_halo = len(halo_global)
+    col_local = np.empty(len(col_global), dtype=np.int32)
+    col_local[owned] = (col_global[owned] - row_begin).astype(np.int32)
+    col_local[~owned] = (n_loc + np.searchsorted(halo_global, col_global[~owned])).astype(np.int32)
+    # owner of every halo column
+    owner = np.searchsorted(ends, halo_global, side="right").astype(np.int32) if n_halo else np.zeros(0, np.int32)
+    if n_halo and np.any((halo_global < starts[owner]) | (halo_global >= ends[owner])):
+        raise ValueError("ranks must own ascending row blocks (rank r before rank r+1)")
+    # everybody learns everybody's wish list; each rank keeps the part it owns
+    wishes = _allgather_arrays(comm, halo_global, np.int64)
+    send_lists = {}
+    for r in range(world):
+        if r == rank:
+            continue
+        w = wishes[r]
+        mine = w[(w >= row_begin) & (w < row_begin + n_loc)]
+        if len(mine):
+            send_lists[r] = (mine - row_begin).astype(np.int32)       # ascending = the receiver's halo order
+    recv_nbr = np.unique(owner) if n_halo else np.zeros(0, np.int32)
+    nbr = np.array(sorted(set(send_lists) | set(int(x) for x in recv_nbr)), dtype=np.int32)
+    recv_off = np.zeros(len(nbr) + 1, dtype=np.int32)
+    send_off = np.zeros(len(nbr) + 1, dtype=np.int32)
+    chunks = []
+    for k, r in enumerate(nbr):
+        recv_off[k + 1] = recv_off[k] + int(np.count_nonzero(owner == r))
+        s = send_lists.get(int(r), np.zeros(0, np.int32))
+        chunks.append(s)
+        send_off[k + 1] = send_off[k] + len(s)
+    send_idx = np.concatenate(chunks) if chunks else np.zeros(0, np.int32)
+    assert recv_off[-1] == n_halo
+    return PartitionPlan(rank, world, n_global, row_begin, n_loc, n_halo, col_local, halo_global, nbr,
+                         recv_off, send_off, send_idx.astype(np.int32))
+
+
+def exchange_halo_host(comm, plan: PartitionPlan, x_owned: np.ndarray) -> np.ndarray:
+    """Reference (host) halo exchange through the control plane: returns x extended by the halo.
+    Used by the CPU tests and by the host-staged transport; production uses RCCL in the library."""
+    packed = x_owned[plan.send_idx] if len(plan.send_idx) else np.zeros(0)
+    meta = np.concatenate([[len(plan.nbr)], plan.nbr, plan.send_off]).astype(np.int64)
+    blobs = comm.allgather_bytes(meta.tobytes() + np.ascontiguousarray(packed, dtype=np.float64).tobytes())
+    x_ext = np.concatenate([x_owned, np.zeros(plan.n_halo)])
+    for k, r in enumerate(plan.nbr):
+        b = blobs[int(r)]
+        nn = int(np.frombuffer(b[:8], dtype=np.int64)[0])
+        hdr = np.frombuffer(b[8:8 * (2 + 2 * nn)], dtype=np.int64)
+        their_nbr, their_off = hdr[:nn], hdr[nn:]
+        data = np.frombuffer(b[8 * (2 + 2 * nn):], dtype=np.float64)
+        j = int(np.nonzero(their_nbr == plan.rank)[0][0])
+        seg = data[their_off[j]:their_off[j + 1]]
+        x_ext[plan.n_loc + plan.recv_off[k]: plan.n_loc + plan.recv_off[k + 1]] = seg
+    return x_ext
+
+
+# --------------------------------------------------------------------------- library glue
+def init_comm(handle: capi.Handle, rank: int, world: int, rdzv) -> None:
+    """RCCL communicators (one for halo send/recv, one for all-reduces) from ids made on rank 0."""
+    L = handle.L
+    ids = C.create_string_buffer(256)
+    if rank == 0:
+        handle.check(L.its_comm_unique_id(ids), "its_comm_unique_id")
+        handle.check(L.its_comm_unique_id(C.byref(ids, 128)), "its_comm_unique_id")
+    blob = rdzv.broadcast(ids.raw if rank == 0 else None)
+    buf = C.create_string_buffer(blob, 256)
+    handle.check(L.its_comm_init(handle.h, rank, world, buf), "its_comm_init")
+
+
+def upload_slab(handle: capi.Handle, comm, n_global: int, row_begin: int, row_ptr, col_global, val,
+                fmt=capi.FMT_CSR_EXACT) -> PartitionPlan:
+    """Plan the partition (collective) and give the local matrix + exchange plan to the library."""
+    n_loc = len(row_ptr) - 1
+    plan = plan_partition(comm, n_global, row_begin, n_loc, col_global)
+    handle.upload_crs(row_ptr, plan.col_local, val, capi.MAT_A, fmt, n_cols=n_loc + plan.n_halo)
+    nbr = np.ascontiguousarray(plan.nbr, dtype=np.int32)
+    so = np.ascontiguousarray(plan.send_off, dtype=np.int32)
+    ro = np.ascontiguousarray(plan.recv_off, dtype=np.int32)
+    si = np.ascontiguousarray(plan.send_idx, dtype=np.int32)
+    handle.check(handle.L.its_dist_setup(handle.h, len(nbr), nbr.ctypes.data_as(C.c_void_p),
+                                         so.ctypes.data_as(C.c_void_p), si.ctypes.data_as(C.c_void_p),
+                                         ro.ctypes.data_as(C.c_void_p)), "its_dist_setup")
+    return plan

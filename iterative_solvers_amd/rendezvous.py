@@ -112,6 +112,19 @@ class Rendezvous:
         _send_msg(self.root, payload)
         return None
 
+    def allgather_bytes(self, payload: bytes) -> list[bytes]:
+        parts = self.gather(payload)
+        if self.rank == 0:
+            hdr = struct.pack(f"<{self.world}Q", *[len(p) for p in parts])
+            blob = self.broadcast(hdr + b"".join(parts))
+        else:
+            blob = self.broadcast(None)
+        lens = struct.unpack(f"<{self.world}Q", blob[:8 * self.world])
+        out, o = [], 8 * self.world
+        for n in lens:
+            out.append(blob[o:o + n]); o += n
+        return out
+
     def barrier(self):
         self.gather(b"b")
         self.broadcast(b"b")

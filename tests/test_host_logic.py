@@ -1,0 +1,125 @@
+"""CPU: host-side mirror (iterative_solvers_amd/solver.py, matgen.py) against the oracle's
+restatement of the reference's preprocessing; C ABI exports every symbol include/its_hip.h
+declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from helpers import MATRICES
+from iterative_solvers_amd import capi, matgen, solver as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "its_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(its_[a-z0-9_]+)\s*\(", hdr)) - {"its_exchange_cb", "its_allreduce_cb"}
+    L = ctypes.CDLL(capi.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
+    capi.lib()
+    assert b"gfx950" in capi.lib().its_version()
+
+
+def test_no_gpu_fails_loudly():
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from iterative_solvers_amd import capi\n"
+            "try:\n    capi.Handle(0)\nexcept capi.ItsError as e:\n    print('RAISED'); sys.exit(0)\n"
+            "print('HANDLE')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout
+    assert "RAISED" in out or "HANDLE" in out          # HANDLE only on a GPU box
+
+
+@pytest.mark.parametrize("name", ["lap2d_16", "lap3d_8", "cd27_6", "pl_200"])
+def test_read_mtx_matches_oracle(name):
+    p = os.path.join(G, name + ".mtx")
+    n, I, J, V = S.read_mtx(p)
+    n2, I2, J2, V2 = orc.read_mtx(p)
+    assert n == n2 and np.array_equal(I, I2) and np.array_equal(J, J2) and np.array_equal(V, V2)
+    rp, col, val = S.coo_to_crs(n, I, J, V)
+    rp2, col2, val2 = MATRICES[name]()
+    assert np.array_equal(rp, rp2) and np.array_equal(col, col2) and np.array_equal(val, val2)
+
+
+def test_read_mtx_symmetric_and_pattern(tmp_path):
+    p = tmp_path / "s.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n% c\n3 3 4\n1 1 2.0\n2 1 -1.0\n3 2 -1.5\n3 3 4.0\n")
+    n, I, J, V = S.read_mtx(str(p))
+    n2, I2, J2, V2 = orc.read_mtx(str(p))
+    assert (n, I.tolist(), J.tolist(), V.tolist()) == (n2, I2.tolist(), J2.tolist(), V2.tolist())
+    assert I.tolist() == [0, 0, 1, 1, 2, 2] and J.tolist() == [0, 1, 0, 2, 1, 2]
+    q = tmp_path / "p.mtx"
+    q.write_text("%%MatrixMarket matrix coordinate pattern general\n2 2 2\n1 1\n2 2\n")
+    n, I, J, V = S.read_mtx(str(q))
+    assert V.tolist() == [0.01, 0.01] == orc.read_mtx(str(q))[3].tolist()       # mmio.h:195-203
+    bad = tmp_path / "b.mtx"
+    bad.write_text("%MatrixMarket matrix coordinate real general\n1 1 1\n1 1 1.0\n")
+    with pytest.raises(ValueError):
+        S.read_mtx(str(bad))                                                      # mmio.h:20
+    assert orc.lib().orc_read_mtx(str(bad).encode(), *[ctypes.byref(ctypes.c_long()) for _ in range(6)]) != 0
+
+
+@pytest.mark.parametrize("scale", ["none", "diag", "max"])
+@pytest.mark.parametrize("name", ["lap2d_16", "pl_200", "cd27_6"])
+def test_scaling_and_split_match_oracle(name, scale):
+    rp, col, val = MATRICES[name]()
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    Vo, rso = orc.scale_coo(n, rows, col, val, scale)
+    Vh, rsh = S.scale_coo(n, rows.astype(np.int64), col.astype(np.int64), val.copy(), scale)
+    assert np.array_equal(Vo, Vh) and np.array_equal(rso, rsh)
+    (a, b, c), (d, e, f) = S.split_L_U(n, rp, col, Vh)
+    (Lp, Lc, Lv), (Up, Uc, Uv) = orc.split_LU(rp, col, Vo)
+    for x, y in ((a, Lp), (b, Lc), (c, Lv), (d, Up), (e, Uc), (f, Uv)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(S.extract_diag(n, rp, col, Vh), orc.extract_diag(rp, col, Vo))
+
+
+def test_stopping_rule_mixes_norms():
+    lp = S.LoopParams(tol=1e-3)
+    assert lp.compute_stopping_criteria("gmres", 2.0, 5.0) == 5e-3          # structs.hpp:52-59
+    assert lp.compute_stopping_criteria("conjugate-gradient", 2.0, 5.0) == 2e-3
+
+
+def test_history_bookkeeping_rules():
+    """record_residual_norm (utility_funcs.hpp:488-502): the converging value is written but the
+    count is not advanced, so the printed list ends one trip early."""
+    a = S.Args("conjugate-gradient", S.LoopParams(max_iters=10, tol=1e-3))
+    a.normed_residuals = np.zeros(11); a.loop_params.stopping_criteria = 1e-3
+    for r in (1.0, 0.1, 1e-4):
+        S._record(a, r); a.loop_params.iter_count += 1
+    assert a.loop_params.residual_count == 2 and a.normed_residuals[2] == 1e-4
+    a.flags.convergence_flag = True
+    S._record(a, 0.5)                                                        # post-loop call overwrites the slot
+    assert a.loop_params.residual_count == 2 and a.normed_residuals[2] == 0.5
+
+
+def test_generators_shapes():
+    rp, col, val = matgen.laplace3d_7pt(8)
+    assert len(rp) - 1 == 512 and len(col) == 7 * 512 - 6 * 64
+    rp, col, val = matgen.convdiff3d_27pt(6)
+    assert len(col) == (3 * 6 - 2) ** 3
+    rp, col, val = matgen.powerlaw(2000)
+    rows = np.repeat(np.arange(2000), np.diff(rp))
+    d = rows == col
+    assert d.sum() == 2000
+    off = np.bincount(rows[~d], weights=np.abs(val[~d]), minlength=2000)
+    assert np.all(val[d] > off)                                             # strictly diagonally dominant
+    for r in range(0, 2000, 97):
+        c = col[rp[r]:rp[r + 1]]
+        assert np.all(np.diff(c) > 0)
+    # slab rows == rows of the global matrix
+    rpg, cg, vg = matgen.laplace3d_7pt(6, nz=12)
+    for z0, z1 in ((0, 4), (4, 9), (9, 12)):
+        rs, cs, vs = matgen.laplace3d_7pt_slab(6, z0, z1, 12)
+        a, b = rpg[z0 * 36], rpg[z1 * 36]
+        assert np.array_equal(cs, cg[a:b].astype(np.int64)) and np.array_equal(vs, vg[a:b])
+        assert np.array_equal(rs, rpg[z0 * 36:z1 * 36 + 1] - a)
