@@ -42,6 +42,28 @@ def cg_iter_bytes(n, nnz):
     return spmv_bytes(n, nnz) + 72 * n
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the kernel from the newest committed PMC summary (profiles/*pmc_summary.txt,
+    produced by tests/profile_run.sh: separate FETCH_SIZE / WRITE_SIZE passes).  gfx950 correction from
+    MI355X_MICROARCH.md: FETCH_SIZE (KB) counts half the bytes of wide coalesced reads -> doubled;
+    WRITE_SIZE (KB) is exact.  None if no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.txt")))
+    if not files:
+        return None
+    fetch = write = None
+    for line in open(files[-1]):
+        if kernel_substr in line:
+            kb = float(line.split("avg=")[1].split("KB")[0])
+            if line.startswith("FETCH_SIZE"):
+                fetch = kb
+            elif line.startswith("WRITE_SIZE"):
+                write = kb
+    if fetch is None or write is None:
+        return None
+    return 2.0 * fetch * 1024 + write * 1024
+
+
 def cpu_baseline(rp, col, val, n, budget_s=15.0):
     """Oracle CG on the host cores, bounded sample (kind 'port': our restatement of the loop)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -133,6 +155,7 @@ def main():
     # same loop without the per-trip read-back (one sync at the end) — reported beside `value`
     res = h.iterate_n(it, a.steps); it += a.steps
     async_ms = h.last_region_ms() / a.steps
+    inloop_spmv_ms = h.last_spmv_ms()          # HIP event pairs around the SpMV launches of that loop
 
     out = None
     if rank == 0:
@@ -141,11 +164,13 @@ def main():
         roof = None
         spmv_all = {}
         if world == 1:
-            h.spmv_timed(xd, yd, fmt, reps=5, with_dot=True)
-            k_ms = h.spmv_timed(xd, yd, fmt, reps=a.spmv_reps, with_dot=True)
+            # the kernel as it runs INSIDE the CG loop (caches in the loop's state): its average
+            # launch duration is what rocprofv3 --stats reports for the same command
+            k_ms = inloop_spmv_ms
             ach = spmv_bytes(n, nnz) / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "kernel": "spmv_stream_kernel<EPI_STORE,DOT>" if fmt == capi.FMT_CSR_EXACT else a.format,
+                    "traffic": pmc_traffic("spmv_stream2_kernel<0, true>") if fmt == capi.FMT_CSR_EXACT else None,
+                    "kernel": "its::spmv_stream2_kernel<0, true> (CSR SpMV + fused p.Ap partials)" if fmt == capi.FMT_CSR_EXACT else a.format,
                     "kernel_ms": k_ms, "algorithmic_bytes": spmv_bytes(n, nnz)}
             for nm, f in (("exact", capi.FMT_CSR_EXACT), ("vector", capi.FMT_CSR_VECTOR)):
                 h.spmv_timed(xd, yd, f, reps=3)

@@ -111,6 +111,9 @@ int its_synchronize(its_handle *h);
 int its_spmv_timed(its_handle *h, int which, const double *x_dev, double *y_dev, int format,
                    int with_dot, int reps, float *avg_ms);
 int its_last_region_ms(its_handle *h, float *ms);
+/* average duration (ms) of the SpMV launch INSIDE the last its_iterate_n CG region (HIP event
+ * pairs around each of the first 256 launches, on the handle's stream) */
+int its_last_spmv_ms(its_handle *h, float *ms);
 /* plan facts: lanes per row chosen, SELL occupancy (nnz / stored elements), row-block count */
 int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occupancy,
                   int *n_row_blocks);

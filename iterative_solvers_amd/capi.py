@@ -55,6 +55,7 @@ SIGNATURES = {
     "its_synchronize": (C.c_int, [C.c_void_p]),
     "its_spmv_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "its_last_region_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "its_last_spmv_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "its_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_int_p, _c_dbl_p, _c_int_p]),
     "its_comm_unique_id": (C.c_int, [C.c_void_p]),
     "its_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -181,6 +182,11 @@ class Handle:
     def last_region_ms(self) -> float:
         ms = C.c_float()
         self.check(self.L.its_last_region_ms(self.h, C.byref(ms)), "its_last_region_ms")
+        return ms.value
+
+    def last_spmv_ms(self) -> float:
+        ms = C.c_float()
+        self.check(self.L.its_last_spmv_ms(self.h, C.byref(ms)), "its_last_spmv_ms")
         return ms.value
 
     def plan_info(self, which=MAT_A, fmt=FMT_CSR_EXACT):

@@ -56,6 +56,7 @@ extern "C" int its_destroy(its_handle *h)
     for (auto &A : h->mat) free_csr(A);
     dfree(h->D); dfree(h->b); dfree(h->r); dfree(h->tmp); dfree(h->x_a); dfree(h->x_b); dfree(h->x);
     dfree(h->p); dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
+    for (auto &e : h->prof_ev) (void)hipEventDestroy(e);
     for (auto &p : h->part) dfree(p);
     dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows);
     if (h->pinned) (void)hipHostFree(h->pinned);
@@ -395,8 +396,11 @@ static int trip_cg(its_handle *h, double *res_out)
     double *rr_in = h->sc + (h->rr_slot ? SC_RR1 : SC_RR0);
     double *rr_out = h->sc + (h->rr_slot ? SC_RR0 : SC_RR1);
     SpmvArgs a; a.x = h->p; a.y = h->tmp; a.dotv = h->p; a.part_sum = h->part[0];
+    const bool prof = h->prof_on && 2 * h->prof_n + 1 < (int)h->prof_ev.size();
+    if (prof) HIPCHK(h, hipEventRecord(h->prof_ev[2 * h->prof_n], h->stream));
     int rc = solver_spmv(h, a, EPI_STORE);                            // cg.hpp:128,160
     if (rc) return rc;
+    if (prof) { HIPCHK(h, hipEventRecord(h->prof_ev[2 * h->prof_n + 1], h->stream)); ++h->prof_n; }
     const double *pq = h->part[0]; int pq_scalar = 0;
     if (its_dist_active(h)) {
         if ((rc = finish_scalar(h, h->part[0], h->sc + SC_PQ, FIN_SUM))) return rc;
@@ -575,6 +579,13 @@ extern "C" int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double
         if (dalloc(h, &h->res_dev, n_trips)) return ITS_EHIP;
         h->res_cap = n_trips;
     }
+    if (h->solver == ITS_CG) {
+        if (h->prof_ev.empty()) {
+            h->prof_ev.resize(512);
+            for (auto &e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
+        }
+        h->prof_n = 0; h->prof_on = true;
+    }
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     for (int i = 0; i < n_trips; ++i) {
         if (h->solver == ITS_CG) rc = trip_cg(h, h->res_dev + i);
@@ -586,6 +597,16 @@ extern "C" int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double
     HIPCHK(h, hipMemcpyAsync(residuals, h->res_dev, (size_t)n_trips * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipEventElapsedTime(&h->last_region_ms, h->ev0, h->ev1));
+    h->prof_on = false;
+    if (h->prof_n > 0) {
+        double tot = 0.0;
+        for (int i = 0; i < h->prof_n; ++i) {
+            float ms = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+            tot += ms;
+        }
+        h->prof_spmv_ms = (float)(tot / h->prof_n);
+    }
     h->last_residual = residuals[n_trips - 1];
     return ITS_OK;
 }
@@ -713,6 +734,13 @@ extern "C" int its_last_region_ms(its_handle *h, float *ms)
 {
     if (!h || !ms) return ITS_EINVAL;
     *ms = h->last_region_ms;
+    return ITS_OK;
+}
+
+extern "C" int its_last_spmv_ms(its_handle *h, float *ms)
+{
+    if (!h || !ms) return ITS_EINVAL;
+    *ms = h->prof_spmv_ms;
     return ITS_OK;
 }
 

@@ -18,6 +18,12 @@ struct its_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_region_ms = 0.f;
+    // in-loop timing of the dominant kernel (SpMV) for bench.py's roofline: event pairs around the
+    // launch inside its_iterate_n
+    std::vector<hipEvent_t> prof_ev;
+    int prof_n = 0;
+    bool prof_on = false;
+    float prof_spmv_ms = 0.f;
     std::string err;
 
     CsrDev mat[3];

@@ -107,10 +107,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream_kernel(
 //   * while one lane per row walks row block rb out of LDS buffer `cur`, the col/val/row_ptr
 //     segment of the NEXT row block is in flight into registers; it is committed to the other
 //     LDS buffer at the top of the next trip.
-//   * gfx950 retires vector-memory operations in issue order (s_waitcnt vmcnt(N) = "all but the
-//     N youngest"), so the x gathers of the walk are issued BEFORE the prefetch loads and the
-//     prefetch loads are unconditional (clamped addresses, CSR_PAD slack): the compiler can
-//     then wait for the gathers with a counted vmcnt that leaves the prefetch in flight.
+//   * measured alternatives that were NOT faster on MI355X (256^3 7-pt): issuing the
+//     x gathers before unconditional prefetch loads so that a counted vmcnt keeps the prefetch
+//     in flight (0.40-0.43 ms vs 0.37 ms), and a wave-autonomous variant without workgroup
+//     barriers (0.41 ms).
 //   * the walk gathers x in batches of 8 entries (the L2 round trips overlap); the fused
 //     multiply-adds still run strictly in CRS order from 0.0 — bit-exact.
 //   * work map (a.map_mode): 0 = each workgroup owns one contiguous run of row blocks
@@ -157,14 +157,19 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
 
 #define S2_ISSUE(d)                                                                       \
     do {                                                                                  \
-        const int iA_ = ((d).z & ~3) + 4 * t, iB_ = iA_ + 4 * ITS_BLOCK;                  \
-        rcA = *reinterpret_cast<const int4 *>(col + iA_);                                 \
-        rvA0 = *reinterpret_cast<const double2 *>(val + iA_);                             \
-        rvA1 = *reinterpret_cast<const double2 *>(val + iA_ + 2);                         \
-        rcB = *reinterpret_cast<const int4 *>(col + iB_);                                 \
-        rvB0 = *reinterpret_cast<const double2 *>(val + iB_);                             \
-        rvB1 = *reinterpret_cast<const double2 *>(val + iB_ + 2);                         \
-        rrp = rp[min((d).x + t, n_rows)];                                                 \
+        const int base_ = (d).z & ~3;                                                     \
+        const int iA_ = base_ + 4 * t, iB_ = iA_ + 4 * ITS_BLOCK;                         \
+        if (iA_ < (d).w) {                                                                \
+            rcA = *reinterpret_cast<const int4 *>(col + iA_);                             \
+            rvA0 = *reinterpret_cast<const double2 *>(val + iA_);                         \
+            rvA1 = *reinterpret_cast<const double2 *>(val + iA_ + 2);                     \
+        }                                                                                 \
+        if (iB_ < (d).w) {                                                                \
+            rcB = *reinterpret_cast<const int4 *>(col + iB_);                             \
+            rvB0 = *reinterpret_cast<const double2 *>(val + iB_);                         \
+            rvB1 = *reinterpret_cast<const double2 *>(val + iB_ + 2);                     \
+        }                                                                                 \
+        if (t < (d).y) rrp = rp[(d).x + t];                                               \
     } while (0)
 #define S2_COMMIT(d, buf)                                                                 \
     do {                                                                                  \
@@ -183,29 +188,13 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         if (t < (d).y) s_rp[buf][t] = rrp;                                                \
         if (t == 0) s_rp[buf][(d).y] = (d).w;                                             \
     } while (0)
-#define S2_BATCH_LOAD(j)                                                                  \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                       \
-        const bool ok_ = (j) + u < j1;                                                    \
-        const int jj_ = ok_ ? (j) + u : 0;                                                \
-        const int cc_ = s_col[cur][jj_];                                                  \
-        c[u] = ok_ ? cc_ : 0;   /* LDS beyond the block's entries is stale: never gather through it */ \
-        v[u] = s_val[cur][jj_];                                                           \
-    }                                                                                     \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
-#define S2_BATCH_FMA(j)                                                                   \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                       \
-        if ((j) + u < j1) {                                                               \
-            if (EPI == EPI_JACOBI_REF && c[u] == row) diag = v[u];                        \
-            else acc = fma(v[u], xv[u], acc);                                             \
-        }                                                                                 \
-    }
 
     int cur = 0;
+    bool have = false;
     int4 d = make_int4(0, 0, 0, 0), dn = d;
     if (niter > 0) {
         d = blk_desc[rb0];
         dn = blk_desc[min(rb0 + rstep, rb_last)];
-        S2_ISSUE(d);
     }
     for (int it = 0; it < niter; ++it) {
         const int rb = rb0 + it * rstep;
@@ -214,33 +203,37 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         const int row = rs + t;
         double acc = 0.0, diag = 0.0;
         const bool lng = d.w - d.z > SPMV_NNZ_MAX;
-        if (!lng) S2_COMMIT(d, cur);
+        if (!lng) {
+            if (!have) S2_ISSUE(d);
+            S2_COMMIT(d, cur);
+        }
         __syncthreads();
-        int j0 = 0, j1 = 0;
-        if (!lng && t < nr) {
-            const int base = d.z & ~3;
-            j0 = s_rp[cur][t] - base; j1 = s_rp[cur][t + 1] - base;
-        }
-        int c[8]; double v[8], xv[8];
-        // first batch of the walk: LDS reads and x gathers go out, THEN the prefetch of the
-        // next row block, THEN the arithmetic (waits for the gathers only)
-        S2_BATCH_LOAD(j0)
-        // operands of the epilogue are fetched with the gathers, not after the prefetch (a load
-        // issued after it could only be waited for together with the whole prefetch)
-        const int rowc = min(row, n_rows - 1);
-        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-        if (EPI == EPI_STORE) { if (DOT) e0 = a.dotv[rowc]; }
-        else if (EPI == EPI_JACOBI_SHIPPED) { e0 = a.D[rowc]; e1 = a.b[rowc]; e2 = a.x[rowc]; }
-        else e0 = a.b[rowc];
-        __builtin_amdgcn_sched_barrier(0);
-        S2_ISSUE(dn);
-        __builtin_amdgcn_sched_barrier(0);
-        S2_BATCH_FMA(j0)
-        for (int j = j0 + 8; j < j1; j += 8) {
-            S2_BATCH_LOAD(j)
-            S2_BATCH_FMA(j)
-        }
-        if (lng) {
+        // the next block's col/val/row_ptr go out before the walk and stay in flight during it
+        have = false;
+        if (it + 1 < niter && dn.w - dn.z <= SPMV_NNZ_MAX) { S2_ISSUE(dn); have = true; }
+        if (!lng) {
+            if (t < nr) {
+                const int base = d.z & ~3;
+                const int j0 = s_rp[cur][t] - base, j1 = s_rp[cur][t + 1] - base;
+                for (int j = j0; j < j1; j += 8) {
+                    int c[8]; double v[8], xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int jj = (j + u < j1) ? j + u : j;
+                        c[u] = s_col[cur][jj]; v[u] = s_val[cur][jj];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (j + u < j1) {
+                            if (EPI == EPI_JACOBI_REF && c[u] == row) diag = v[u];
+                            else acc = fma(v[u], xv[u], acc);
+                        }
+                    }
+                }
+            }
+        } else {
             // a single row longer than the LDS capacity: stream it through buffer `cur` in
             // chunks; lane 0 keeps the in-order chain.  (Rare: power-law tails.)
             for (int c0 = d.z; c0 < d.w; c0 += SPMV_NNZ_MAX) {
@@ -268,19 +261,20 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         if (t < nr) {
             if (EPI == EPI_STORE) {
                 a.y[row] = acc;
-                if (DOT) lane_sum = fma(acc, e0, lane_sum);
+                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
             } else if (EPI == EPI_RESIDUAL) {
-                const double r = e0 - acc;
+                const double r = a.b[row] - acc;
                 a.y[row] = r;
                 lane_sum = fma(r, r, lane_sum);
                 lane_max = fmax(lane_max, fabs(r));
             } else if (EPI == EPI_JACOBI_SHIPPED) {
-                const double adj = fma(-e0, acc, e2);
-                a.y[row] = (e1 - adj) / e0;
+                const double dd = a.D[row];
+                const double adj = fma(-dd, acc, a.x[row]);
+                a.y[row] = (a.b[row] - adj) / dd;
             } else if (EPI == EPI_JACOBI_REF) {
-                a.y[row] = (e0 - acc) / diag;
+                a.y[row] = (a.b[row] - acc) / diag;
             } else if (EPI == EPI_GS_RHS) {
-                a.y[row] = fma(-1.0, acc, e0);
+                a.y[row] = fma(-1.0, acc, a.b[row]);
             }
         }
         cur ^= 1;
@@ -288,8 +282,6 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
     }
 #undef S2_ISSUE
 #undef S2_COMMIT
-#undef S2_BATCH_LOAD
-#undef S2_BATCH_FMA
     if (DOT || EPI == EPI_RESIDUAL) {
         const double bs = block_sum(lane_sum, s_red);
         if (t == 0 && a.part_sum) {

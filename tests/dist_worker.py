@@ -1,0 +1,103 @@
+"""One rank of the multi-process GPU test (tests/test_gpu_distributed.py).  All ranks share GPU 0 and
+use the library's HOST test transport: halo entries and scalars cross ranks through the TCP
+rendezvous, everything else (pack, interior/boundary split SpMV, fused updates) runs on the GPU
+exactly as with RCCL.  Writes <out>.<rank>.json."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from iterative_solvers_amd import capi, distributed as D, matgen  # noqa: E402
+from iterative_solvers_amd.rendezvous import Rendezvous  # noqa: E402
+
+XCB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
+RCB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+
+def main():
+    kind, solver, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    rdzv = Rendezvous()
+    rank, world = rdzv.rank, rdzv.world
+
+    def exchange(user, send, send_off, recv, recv_off, nbr, n_nbr):
+        try:
+            nb = [nbr[k] for k in range(n_nbr)]
+            so = [send_off[k] for k in range(n_nbr + 1)]
+            data = np.ctypeslib.as_array(send, (max(so[-1], 1),))[:so[-1]] if n_nbr else np.zeros(0)
+            meta = np.array([n_nbr] + nb + so, dtype=np.int64)
+            blobs = rdzv.allgather_bytes(meta.tobytes() + np.ascontiguousarray(data).tobytes())
+            for k in range(n_nbr):
+                b = blobs[nb[k]]
+                nn = int(np.frombuffer(b[:8], dtype=np.int64)[0])
+                hdr = np.frombuffer(b[8:8 * (2 + 2 * nn)], dtype=np.int64)
+                their_nbr, their_off = hdr[:nn], hdr[nn:]
+                payload = np.frombuffer(b[8 * (2 + 2 * nn):], dtype=np.float64)
+                j = int(np.nonzero(their_nbr == rank)[0][0])
+                seg = payload[their_off[j]:their_off[j + 1]]
+                assert len(seg) == recv_off[k + 1] - recv_off[k]
+                for i, v in enumerate(seg):
+                    recv[recv_off[k] + i] = v
+            return 0
+        except Exception:  # noqa: BLE001
+            import traceback; traceback.print_exc()
+            return 1
+
+    def allreduce(user, vals, count, op):
+        try:
+            mine = np.array([vals[i] for i in range(count)])
+            parts = [np.frombuffer(b, dtype=np.float64) for b in rdzv.allgather_bytes(mine.tobytes())]
+            res = np.max(parts, axis=0) if op == 1 else np.sum(parts, axis=0)   # rank order: deterministic
+            for i in range(count):
+                vals[i] = res[i]
+            return 0
+        except Exception:  # noqa: BLE001
+            import traceback; traceback.print_exc()
+            return 1
+
+    xcb, rcb = XCB(exchange), RCB(allreduce)
+    if kind == "lap":
+        N, NZ = 12, 24
+        cuts = np.linspace(0, NZ, world + 1).astype(int)
+        cuts[1:-1] += np.arange(1, world) % 2                          # uneven slabs
+        z0, z1 = int(cuts[rank]), int(cuts[rank + 1])
+        rp, colg, val = matgen.laplace3d_7pt_slab(N, z0, z1, NZ)
+        row_begin, n_global = z0 * N * N, NZ * N * N
+        diag = np.full(len(rp) - 1, 6.0)
+    else:
+        rpg, cg, vg = matgen.powerlaw(6000)
+        n_global = 6000
+        cuts = np.linspace(0, n_global, world + 1).astype(int)
+        r0, r1 = int(cuts[rank]), int(cuts[rank + 1])
+        a, b = rpg[r0], rpg[r1]
+        rp = (rpg[r0:r1 + 1] - a).astype(np.int32); colg = cg[a:b].astype(np.int64); val = vg[a:b].copy()
+        row_begin = r0
+        rows = np.repeat(np.arange(r0, r1), np.diff(rp))
+        diag = np.zeros(r1 - r0); m = rows == colg; diag[rows[m] - r0] = val[m]
+    n_loc = len(rp) - 1
+    h = capi.Handle(0)
+    h.check(h.L.its_comm_init_host(h.h, rank, world, C.cast(xcb, C.c_void_p), C.cast(rcb, C.c_void_p), None), "its_comm_init_host")
+    plan = D.upload_slab(h, rdzv, n_global, row_begin, rp, colg, val, capi.FMT_CSR_EXACT)
+    h.upload_vectors(diag, np.ones(n_loc), np.ones(n_loc))
+    r0_inf, r0_two = h.init_residual()
+    kindmap = {"cg": capi.CG, "jacobi": capi.JACOBI, "gmres": capi.GMRES}
+    h.solver_setup(kindmap[solver], restart_len=10, jacobi_mode=capi.JACOBI_REF)
+    trips = 30
+    hist = []
+    for it in range(trips):
+        hist.append(h.iterate(it))
+        if solver == "gmres" and (it + 1) % 10 == 0 and it + 1 < trips:
+            h.gmres_restart(it)
+    x = h.download_x(n_loc, trips)
+    json.dump({"rank": rank, "row_begin": row_begin, "n_loc": n_loc, "n_halo": plan.n_halo, "nbr": plan.nbr.tolist(),
+               "r0_inf": r0_inf, "r0_two": r0_two, "hist": hist, "x": x.tolist()}, open(f"{out}.{rank}.json", "w"))
+    rdzv.barrier()
+    h.close(); rdzv.close()
+
+
+if __name__ == "__main__":
+    main()
