@@ -65,6 +65,14 @@ int its_init_residual(its_handle *h, double *r0_inf, double *r0_two);
 int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precond_kind,
                      int jacobi_mode, int gs_order);
 
+/* Options (set before its_solver_setup):
+ *   "gmres_givens" 0 = least squares by O(m) Givens rotation updates on the host (default, fast);
+ *                  1 = the reference's formulation product for product (dense (m+1)^2 products
+ *                      J, Q <- J Q, R = Q H, g = Q beta e1, methods/gmres.hpp:427-658): O(m^3) host
+ *                      work per trip, reproduces the reference's |g[k+1]| also BELOW the attainable
+ *                      accuracy, where the rotation form keeps shrinking and the dense form stalls. */
+int its_set_option(its_handle *h, const char *name, int value);
+
 /* ---- the loop body (solver_harness.hpp:40-116) -------------------------------------- */
 /* Solver::iterate + record_residual_norm's value + Solver::exchange_arrays
  * (solver_harness.hpp:43-90).  Blocks until the scalar is on the host.  *residual_norm is what

@@ -36,6 +36,7 @@ SIGNATURES = {
     "its_upload_vectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "its_init_residual": (C.c_int, [C.c_void_p, _c_dbl_p, _c_dbl_p]),
     "its_solver_setup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "its_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "its_iterate": (C.c_int, [C.c_void_p, C.c_int, _c_dbl_p]),
     "its_iterate_n": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "its_gmres_restart": (C.c_int, [C.c_void_p, C.c_int]),
@@ -140,6 +141,9 @@ class Handle:
 
     def solver_setup(self, kind, restart_len=100, precond=PRECOND_NONE, jacobi_mode=JACOBI_SHIPPED, gs_order=GS_LEVEL):
         self.check(self.L.its_solver_setup(self.h, kind, restart_len, precond, jacobi_mode, gs_order), "its_solver_setup")
+
+    def set_option(self, name: str, value: int):
+        self.check(self.L.its_set_option(self.h, name.encode(), value), "its_set_option")
 
     def iterate(self, iter_count: int) -> float:
         r = C.c_double()

@@ -193,6 +193,18 @@ extern "C" int its_upload_crs(its_handle *h, int which, int n_rows, int n_cols, 
     return rc;
 }
 
+extern "C" int its_set_option(its_handle *h, const char *name, int value)
+{
+    if (!h || !name) return ITS_EINVAL;
+    if (!strcmp(name, "gmres_givens")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "gmres_givens: 0 (rotations) or 1 (reference dense products)");
+        if (h->setup_done && h->solver == ITS_GMRES) FAIL(h, ITS_ESTATE, "set gmres_givens before its_solver_setup");
+        h->gmres_givens = value;
+        return ITS_OK;
+    }
+    FAIL(h, ITS_EINVAL, std::string("unknown option ") + name);
+}
+
 extern "C" int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occ, int *n_row_blocks)
 {
     if (!h || which < 0 || which > 2 || !h->have[which]) return ITS_EINVAL;
@@ -369,6 +381,12 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         if (dalloc(h, &h->V, ne * (size_t)(m + 1)) || dalloc(h, &h->hcol_dev, m + 2) || dalloc(h, &h->y_dev, m + 1)) return ITS_EHIP;
         h->Rm.assign((size_t)(m + 1) * m, 0.0); h->g.assign(m + 1, 0.0);
         h->cs.assign(m, 0.0); h->sn.assign(m, 0.0); h->hcol.assign(m + 2, 0.0);
+        if (const char *e = getenv("ITS_GMRES_GIVENS")) h->gmres_givens = !strcmp(e, "dense") || !strcmp(e, "1");
+        if (h->gmres_givens == 1) {
+            h->Hd.assign((size_t)(m + 1) * m, 0.0); h->Ht = h->Hd; h->Rd = h->Hd;
+            h->Qd.assign((size_t)(m + 1) * (m + 1), 0.0); h->Jd = h->Qd; h->Qc = h->Qd;
+            for (int i = 0; i <= m; ++i) h->Qd[(size_t)i * (m + 1) + i] = 1.0;
+        }
         h->restart_count = 0;
         // beta = ||r||, V[0] = r * (1/beta)   (gmres.hpp:734-736,768-771)
         launch_dot_partials(h->r, h->r, n, h->part[0], h->stream);
@@ -484,11 +502,44 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->pinned, h->hcol_dev, (size_t)(k + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    // ---- host: Givens least squares (gmres.hpp:427-658) as O(k) rotation updates.  The
-    // reference forms Q = J_k...J_0 and R = Q H with dense products; applying the stored
-    // rotations to the new column gives the same R[:,k] and g up to round-off.
     double *hc = h->hcol.data();
     for (int i = 0; i <= k + 1; ++i) hc[i] = h->pinned[i];
+    if (h->gmres_givens == 1) {
+        // ---- the reference's formulation, product for product (gmres.hpp:427-658): J = I with
+        // one 2x2 block, H_tmp = Q H, Q <- J Q, R = Q H, g = Q (beta e1), every entry a fused
+        // chain over the full (m+1) range.  O(m^3) per trip on the host, but its rounding — in
+        // particular the stagnation of |g[k+1]| at ~eps*beta once converged — is the reference's,
+        // so iteration counts at TOL below the attainable accuracy match the shipped binary.
+        const int m1 = m + 1;
+        auto mm = [](const double *A, const double *B, double *C, int nrA, int ncA, int ncB) {
+            for (int i = 0; i < nrA; ++i)
+                for (int j = 0; j < ncB; ++j) {
+                    double t = 0.0;
+                    for (int q = 0; q < ncA; ++q) t = std::fma(A[(size_t)i * ncA + q], B[(size_t)q * ncB + j], t);
+                    C[(size_t)i * ncB + j] = t;
+                }
+        };
+        for (int i = 0; i <= k + 1; ++i) h->Hd[(size_t)i * m + k] = hc[i];          // H row-major (m+1) x m, column k
+        std::fill(h->Jd.begin(), h->Jd.end(), 0.0);
+        for (int i = 0; i < m1; ++i) h->Jd[(size_t)i * m1 + i] = 1.0;
+        if (k == 0) h->Ht = h->Hd; else mm(h->Qd.data(), h->Hd.data(), h->Ht.data(), m1, m1, m);
+        const double hkk = h->Ht[(size_t)k * m + k], hk1 = h->Ht[(size_t)(k + 1) * m + k];
+        const double denom = std::sqrt(std::fma(hkk, hkk, hk1 * hk1));
+        const double c = hkk / denom, s = hk1 / denom;
+        h->Jd[(size_t)k * m1 + k] = c;            h->Jd[(size_t)k * m1 + k + 1] = s;
+        h->Jd[(size_t)(k + 1) * m1 + k] = -1.0 * s; h->Jd[(size_t)(k + 1) * m1 + k + 1] = c;
+        mm(h->Jd.data(), h->Qd.data(), h->Qc.data(), m1, m1, m1);
+        h->Qd = h->Qc;
+        mm(h->Qd.data(), h->Hd.data(), h->Rd.data(), m1, m1, m);
+        for (int i = 0; i < m1; ++i) h->g[i] = h->Qd[(size_t)i * m1] * h->beta;   // Q (beta e1): the chain's other terms are exact zeros
+        for (int c2 = 0; c2 <= k; ++c2)                                           // keep Rm (col-major) for gmres_get_x
+            for (int i = 0; i <= c2; ++i) h->Rm[(size_t)c2 * m1 + i] = h->Rd[(size_t)i * m + c2];
+        *res_host = std::fabs(h->g[k + 1]);
+        return ITS_OK;
+    }
+    // ---- default: Givens least squares (gmres.hpp:427-658) as O(k) rotation updates.  The
+    // reference forms Q = J_k...J_0 and R = Q H with dense products; applying the stored
+    // rotations to the new column gives the same R[:,k] and g up to round-off.
     for (int i = 0; i < k; ++i) {
         const double t0 = h->cs[i] * hc[i] + h->sn[i] * hc[i + 1];
         const double t1 = -h->sn[i] * hc[i] + h->cs[i] * hc[i + 1];
@@ -637,6 +688,11 @@ extern "C" int its_gmres_restart(its_handle *h, int iter_count)
     h->beta = h->pinned[0];
     std::fill(h->g.begin(), h->g.end(), 0.0); h->g[0] = h->beta;
     std::fill(h->Rm.begin(), h->Rm.end(), 0.0);
+    if (h->gmres_givens == 1) {                                        // init_gmres_structs (gmres.hpp:773-779)
+        std::fill(h->Hd.begin(), h->Hd.end(), 0.0);
+        std::fill(h->Qd.begin(), h->Qd.end(), 0.0);
+        for (int i = 0; i <= h->m; ++i) h->Qd[(size_t)i * (h->m + 1) + i] = 1.0;
+    }
     ++h->restart_count;
     return ITS_OK;
 }

@@ -42,6 +42,9 @@ struct its_handle {
     int m = 0, restart_count = 0;
     double beta = 0.0;
     std::vector<double> Rm, g, cs, sn, hcol;   // host: R (col-major (m+1) x m), g, Givens c/s
+    // dense least-squares state of the reference formulation (gmres_givens == 1)
+    std::vector<double> Hd, Qd, Jd, Qc, Ht, Rd;
+    int gmres_givens = 0;                 // 0: O(m) rotation updates, 1: the reference's dense products
     // reductions / scalars
     double *part[4] = {nullptr, nullptr, nullptr, nullptr};
     double *sc = nullptr;                 // SC_COUNT device scalars

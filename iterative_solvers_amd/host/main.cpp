@@ -1,0 +1,58 @@
+// main.cpp — its_solve: the reference's driver (main.cpp:96-593) with the hot path on an MI355X.
+//   its_solve file.mtx -j|-gs|-cg|-gm [-p j|gs] [-scale max|diag|none]
+// Same flow (read -> preprocessing -> solve -> postprocessing), same stdout; all per-iteration
+// work happens behind the C ABI of libits_hip.so.
+#include "io_funcs.hpp"
+#include "solver_harness.hpp"
+
+template <typename VT>
+void preprocessing(argType *args, Solver<VT> *solver)
+{
+    std::cout << "Preprocessing Matrix Data" << std::endl;
+    args->timers.preprocessing_wtime.start_stopwatch();
+    std::vector<double> scaling_row_elems;
+    scale_matrix(args->coo_mat, args->scale_type, scaling_row_elems);            // main.cpp:117-132
+    args->vec_size = (int)args->coo_mat.n_cols;
+    std::cout << "Allocating space for general CPU structs" << std::endl;
+    args->normed_residuals.assign(args->loop_params.max_iters / args->loop_params.residual_check_len + 1, 0.0);
+    convert_to_crs(args->coo_mat, args->crs_mat);                                // main.cpp:221-229
+    solver->allocate_cpu_solver_structs(args);                                   // main.cpp:206-218
+    extract_diag(args->coo_mat, solver->D);                                      // main.cpp:268
+    generate_vector(solver->b, args->vec_size, args->loop_params.init_b);        // main.cpp:271-276
+    scale_vector(solver->b, scaling_row_elems);
+    generate_vector(solver->x_old, args->vec_size, args->loop_params.init_x);
+    scale_vector(solver->x_old, scaling_row_elems);
+    solver->upload_vectors();
+    double r0_inf = 0, r0_two = 0;
+    solver->init_residual(&r0_inf, &r0_two);                                     // main.cpp:307
+    solver->gmres_restart_length = args->loop_params.gmres_restart_len;
+    solver->init_structs();                                                      // main.cpp:317
+    args->loop_params.stopping_criteria = args->loop_params.compute_stopping_criteria(args->solver_type, r0_inf, r0_two);   // :319
+    args->timers.preprocessing_wtime.end_stopwatch();
+}
+
+template <typename VT>
+void run_solver(int argc, char *argv[])
+{
+    argType *args = new argType;
+    args->timers.total_wtime.start_stopwatch();
+    assign_cli_inputs(args, argc, argv);
+    // Run-time overrides of the config.mk values (extension; the reference needs a rebuild)
+    if (const char *e = getenv("ITS_MAX_ITERS")) args->loop_params.max_iters = atoi(e);
+    if (const char *e = getenv("ITS_TOL")) args->loop_params.tol = atof(e);
+    if (const char *e = getenv("ITS_GMRES_RESTART_LEN")) args->loop_params.gmres_restart_len = atoi(e);
+    Solver<VT> *solver = new Solver<VT>(args->solver_type, args->preconditioner_type);
+    std::cout << "Reading Matrix" << std::endl;
+    read_mtx(args->matrix_file_name, &args->coo_mat);
+    preprocessing<VT>(args, solver);
+    solve<VT>(args, solver);
+    postprocessing(args);
+    delete solver;
+    delete args;
+}
+
+int main(int argc, char *argv[])
+{
+    run_solver<double>(argc, argv);
+    return 0;
+}

@@ -1,0 +1,64 @@
+"""GPU: the C++ host driver (iterative_solvers_amd/host/its_solve — the reference's main.cpp /
+solver_harness.hpp / solver.hpp shape over the C ABI) against golden output captured from the
+UNMODIFIED compiled reference (tests/golden/reference_histories.json), same .mtx, same CLI."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+EXE = os.path.join(os.path.dirname(HERE), "iterative_solvers_amd", "host", "its_solve")
+HIST = json.load(open(os.path.join(G, "reference_histories.json")))
+LINE = re.compile(r"\|\|A\*x_(\d+) - b\|\|_infty = (\S+)")
+
+CASES = [k for k in sorted(HIST) if k.split("|")[0] in ("lap2d_16", "lap3d_8", "cd27_6", "pl_200")]
+
+
+@pytest.mark.parametrize("key", CASES)
+def test_cli_matches_reference_output(key):
+    """The golden histories were printed by the reference at its compiled-in TOL = 1e-14, where
+    the last trips of a converging run are rounding noise (tests/test_gpu_solvers.py docstring).
+    The driver is therefore run at ITS_TOL = 1e-10: its arithmetic up to the stopping trip is the
+    same, so the golden list must be reproduced up to the first value below 1e-10*||r0|| and the
+    run must stop exactly there (iteration count +-1 %)."""
+    assert os.path.exists(EXE), "build it: make -C iterative_solvers_amd/host"
+    m, s, sc, mm, pp = key.split("|")
+    restart, pre = int(mm[1:]), pp[1:]
+    exp = HIST[key]
+    cmd = [EXE, os.path.join(G, m + ".mtx"), s] + (["-p", pre] if pre else ["-scale", sc])
+    env = dict(os.environ, ITS_GMRES_RESTART_LEN=str(restart), ITS_TOL="1e-10")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    hist = np.array([float(v) for _, v in LINE.findall(txt)])
+    want = np.array(exp["history"])
+    conv = re.search(r"solver converged in: (\d+) iterations", txt)
+    stop = float(re.search(r"is: (\S+)\n", txt).group(1))
+    stop10 = exp["stopping"] * 1e4
+    assert abs(stop - stop10) <= 1e-12 * stop10
+    below = np.nonzero(want <= stop10)[0]
+    if below.size:                                   # the reference passes 1e-10*||r0|| at trip below[0]
+        kstar = int(below[0])
+        assert conv is not None, txt[-400:]
+        assert abs(int(conv.group(1)) - (kstar + 1)) <= max(1, round(0.01 * (kstar + 1)))
+        k = min(len(hist), kstar)
+    else:
+        k = min(len(hist), len(want))
+        if exp["n_lines"] <= 300 and np.all(np.isfinite(want)):
+            assert conv is None or int(conv.group(1)) > len(want)
+    if k:
+        w, g = want[:k], hist[:k]
+        ok = np.isfinite(w) & (w < 1e100)
+        r0 = stop10 / 1e-10
+        bound = np.maximum(1e-10 * np.maximum(w[ok], 1e-2 * r0), 2e-15 * w[ok])
+        # restarted GMRES(10) amplifies rounding noise by ~1e7: the reference itself moves 3-4 % under a
+        # change of its reduction order (measured, see test_gpu_solvers.py); 5 % there
+        if s == "-gm" and restart == 10:
+            bound = np.maximum(bound, 5e-2 * w[ok])
+        bad = np.nonzero(np.abs(g[ok] - w[ok]) > bound)[0]
+        assert bad.size == 0, (key, int(bad[0]), float(g[ok][bad[0]]), float(w[ok][bad[0]]))
