@@ -37,10 +37,11 @@ enum { ITS_PRECOND_NONE = 0, ITS_PRECOND_JACOBI = 1, ITS_PRECOND_GS = 2 };
 enum { ITS_FMT_CSR_EXACT = 0, ITS_FMT_CSR_VECTOR = 1, ITS_FMT_SELL = 2 };
 /* which matrix of SparseMtxFormat<VT> (sparse_matrix.hpp:352-394) an upload fills */
 enum { ITS_MAT_A = 0, ITS_MAT_L = 1, ITS_MAT_U = 2 };
-/* Gauss-Seidel sweep order.  NATURAL = the reference's serial forward substitution order
- * (kernels.hpp:451-473) executed level by level (rows of one dependency level in parallel:
- * identical arithmetic per row, hence identical iterates); MULTICOLOR = greedy colouring,
- * rows of one colour in parallel (a different splitting unless the caller pre-permutes). */
+/* Gauss-Seidel sweep order.  The library always executes the reference's forward substitution
+ * (kernels.hpp:451-473) level by level (rows of one dependency level in parallel: identical
+ * arithmetic per row, hence identical iterates).  ITS_GS_MULTICOLOR is a HOST-side choice: the
+ * caller permutes the system with its_multicolor_order / its_permute_crs before uploading (the
+ * Python and C++ hosts do), after which levels == colours.  its_solver_setup records the value. */
 enum { ITS_GS_LEVEL = 0, ITS_GS_MULTICOLOR = 1 };
 
 /* ---- library / handle --------------------------------------------------------------- */
@@ -125,6 +126,19 @@ int its_last_spmv_ms(its_handle *h, float *ms);
 /* plan facts: lanes per row chosen, SELL occupancy (nnz / stored elements), row-block count */
 int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occupancy,
                   int *n_row_blocks);
+
+/* ---- Gauss-Seidel ordering helpers (host only, no GPU needed) -------------------------
+ * methods/gauss_seidel.hpp sweeps in natural order; its_solver_setup schedules that sweep by
+ * dependency level.  For a MULTICOLOUR sweep the caller permutes the system symmetrically with
+ * the order below (rows colour by colour) and uploads P A P^T, P b, P x0: the levels of the
+ * permuted strict-lower part are then the colours, and a CPU reference run on the same permuted
+ * matrix performs the identical arithmetic. */
+/* greedy distance-1 colouring of the graph of A + A^T in natural vertex order;
+ * perm_new2old[n]: rows listed colour by colour, ascending inside a colour */
+int its_multicolor_order(int n, const int *row_ptr, const int *col, int *perm_new2old, int *n_colors);
+/* B = P A P^T in CRS, columns ascending inside a row (outputs sized like the inputs) */
+int its_permute_crs(int n, const int *row_ptr, const int *col, const double *val, const int *perm_new2old,
+                    int *row_ptr_out, int *col_out, double *val_out);
 
 /* ---- multi-GPU (no counterpart in the reference, which is single-process:
  * "TODO: MPI preprocessing will go here", main.cpp:94) ----------------------------------------

@@ -58,6 +58,8 @@ SIGNATURES = {
     "its_last_region_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "its_last_spmv_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "its_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_int_p, _c_dbl_p, _c_int_p]),
+    "its_multicolor_order": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _c_int_p]),
+    "its_permute_crs": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "its_comm_unique_id": (C.c_int, [C.c_void_p]),
     "its_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "its_comm_init_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -86,6 +88,30 @@ def lib() -> C.CDLL:
 
 class ItsError(RuntimeError):
     pass
+
+
+def multicolor_order(row_ptr, col):
+    """Host-only: (perm_new2old, n_colors) of the greedy colouring (its_multicolor_order)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32); col = np.ascontiguousarray(col, dtype=np.int32)
+    n = len(row_ptr) - 1
+    perm = np.empty(n, dtype=np.int32); nc = C.c_int()
+    rc = lib().its_multicolor_order(n, row_ptr.ctypes.data, col.ctypes.data, perm.ctypes.data, C.byref(nc))
+    if rc != 0:
+        raise ItsError(f"its_multicolor_order failed ({rc})")
+    return perm, nc.value
+
+
+def permute_crs(row_ptr, col, val, perm_new2old):
+    """Host-only: P A P^T (its_permute_crs)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32); col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64); perm = np.ascontiguousarray(perm_new2old, dtype=np.int32)
+    n = len(row_ptr) - 1
+    rp = np.empty(n + 1, np.int32); c = np.empty(len(col), np.int32); v = np.empty(len(col))
+    rc = lib().its_permute_crs(n, row_ptr.ctypes.data, col.ctypes.data, val.ctypes.data, perm.ctypes.data,
+                               rp.ctypes.data, c.ctypes.data, v.ctypes.data)
+    if rc != 0:
+        raise ItsError(f"its_permute_crs failed ({rc})")
+    return rp, c, v
 
 
 def _ptr(a: np.ndarray):

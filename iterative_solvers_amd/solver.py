@@ -146,10 +146,18 @@ class Solver:
         self.n = 0
         self.x_star = None
         self.gmres_restart_length = 100
+        self.perm = None               # multicolour ordering (new -> old) when gs_order == GS_MULTICOLOR
+        self.n_colors = 0
 
     # allocate_cpu_solver_structs + convert_to_crs + extract_diag (main.cpp:206-229,268)
     def upload(self, row_ptr, col, val, b, x0):
         n = self.n = len(row_ptr) - 1
+        if self.solver_type == "gauss-seidel" and self.gs_order == capi.GS_MULTICOLOR:
+            # multicolour sweep = the reference's natural-order sweep on P A P^T with rows ordered
+            # colour by colour (include/its_hip.h, "Gauss-Seidel ordering helpers")
+            self.perm, self.n_colors = capi.multicolor_order(row_ptr, col)
+            row_ptr, col, val = capi.permute_crs(row_ptr, col, val, self.perm)
+            b = np.asarray(b)[self.perm]; x0 = np.asarray(x0)[self.perm]
         self.handle.upload_crs(row_ptr, col, val, capi.MAT_A, self.spmv_format)
         need_L = self.solver_type == "gauss-seidel" or (self.solver_type == "gmres" and self.preconditioner_type == "gauss-seidel")
         if need_L:                                                     # gauss_seidel.hpp:249-630
@@ -177,7 +185,10 @@ class Solver:
         self.handle.gmres_restart(iter_count)
 
     def save_x_star(self, iter_count: int):                            # solver.hpp:658-726
-        self.x_star = self.handle.download_x(self.n, iter_count)
+        x = self.handle.download_x(self.n, iter_count)
+        if self.perm is not None:
+            out = np.empty_like(x); out[self.perm] = x; x = out
+        self.x_star = x
         return self.x_star
 
 

@@ -143,3 +143,30 @@ def test_jacobi_ref_correct_mode(name):
     ref, args, xs = run_both(name, "-j", "none", max_iters=200, jacobi_mode=1)
     check_history(ref, args)
     assert np.max(np.abs(xs - ref["x_star"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["x_star"])))
+
+
+@pytest.mark.parametrize("name", ["lap2d_16", "lap3d_16", "cd27_12", "pl_5000"])
+def test_gauss_seidel_multicolor(name):
+    """Multicolour GS: the library sweeps P A P^T (rows colour by colour) level by level, so the
+    levels are the colours; the oracle's natural-order sweep on the SAME permuted matrix is the
+    identical arithmetic (SURVEY.md §7 "GS ordering")."""
+    orc.set_threads(1)
+    rp, col, val = MATRICES[name]()
+    n = len(rp) - 1
+    perm, nc = capi.multicolor_order(rp, col)
+    rpp, cp, vp = capi.permute_crs(rp, col, val, perm)
+    b = np.ones(n)
+    ref = orc.solve(rpp, cp, vp, b, b.copy(), orc.GAUSS_SEIDEL, max_iters=120, tol=1e-10)
+    ref["noise"] = np.zeros(len(ref["history"]))
+    args = S.Args("gauss-seidel", S.LoopParams(max_iters=120, tol=1e-10), S.Flags(), "", "none")
+    sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_MULTICOLOR)
+    try:
+        S.preprocessing_crs(args, sol, rp, col, val, b, b.copy())
+        assert sol.n_colors == nc and sol.n_colors <= {"lap2d_16": 2, "lap3d_16": 2, "cd27_12": 8}.get(name, 64)
+        S.solve(args, sol)
+        xs = sol.x_star.copy()
+    finally:
+        sol.handle.close()
+    check_history(ref, args)
+    x_ref = np.empty(n); x_ref[perm] = ref["x_star"]
+    assert np.max(np.abs(xs - x_ref)) <= 1e-12 * max(1.0, np.max(np.abs(x_ref)))

@@ -123,3 +123,24 @@ def test_generators_shapes():
         a, b = rpg[z0 * 36], rpg[z1 * 36]
         assert np.array_equal(cs, cg[a:b].astype(np.int64)) and np.array_equal(vs, vg[a:b])
         assert np.array_equal(rs, rpg[z0 * 36:z1 * 36 + 1] - a)
+
+
+@pytest.mark.parametrize("name", ["lap2d_16", "lap3d_8", "cd27_6", "pl_200"])
+def test_multicolor_order_is_valid(name):
+    rp, col, val = MATRICES[name]()
+    n = len(rp) - 1
+    perm, nc = capi.multicolor_order(rp, col)
+    assert sorted(perm.tolist()) == list(range(n))
+    rpp, cp, vp = capi.permute_crs(rp, col, val, perm)
+    # P A P^T has the same entries: x -> P x commutes with the product
+    x = np.random.default_rng(0).uniform(-1, 1, n)
+    y = orc.spmv(rp, col, val, x)
+    yp = orc.spmv(rpp, cp, vp, x[perm])
+    assert np.allclose(yp, y[perm], rtol=1e-13, atol=1e-13)
+    # dependency levels of the strict lower part == colours (rows of one colour are independent)
+    lev = np.zeros(n, dtype=int)
+    for i in range(n):
+        c = cp[rpp[i]:rpp[i + 1]]; c = c[c < i]
+        lev[i] = lev[c].max() + 1 if len(c) else 0
+    assert lev.max() + 1 <= nc
+    assert nc <= {"lap2d_16": 2, "lap3d_8": 2, "cd27_6": 8}.get(name, 64)
