@@ -172,8 +172,12 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     if (dalloc(h, &A.blk_row, blk.size())) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.blk_row, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
     std::vector<int4> desc(std::max(A.n_blocks, 1));
-    for (int i = 0; i < A.n_blocks; ++i)
-        desc[i] = make_int4(blk[i], blk[i + 1] - blk[i], row_ptr[blk[i]], row_ptr[blk[i + 1]]);
+    for (int i = 0; i < A.n_blocks; ++i) {
+        // .y = rows | (longest row of the block, capped) << 16: the kernel's batch count
+        int longest = 0;
+        for (int r = blk[i]; r < blk[i + 1]; ++r) longest = std::max(longest, row_ptr[r + 1] - row_ptr[r]);
+        desc[i] = make_int4(blk[i], (blk[i + 1] - blk[i]) | (std::min(longest, 0x7fff) << 16), row_ptr[blk[i]], row_ptr[blk[i + 1]]);
+    }
     if (dalloc(h, &A.blk_desc, desc.size())) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.blk_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
     A.lanes_per_row = pick_lanes_per_row(n_rows, nnz);
@@ -201,6 +205,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         if (h->setup_done && h->solver == ITS_GMRES) FAIL(h, ITS_ESTATE, "set gmres_givens before its_solver_setup");
         h->gmres_givens = value;
         return ITS_OK;
+    }
+    {
+        const int rc = spmv_tune(name, value);      // process-wide launch tunables of the exact SpMV
+        if (rc == 0) return ITS_OK;
+        if (rc == -1) FAIL(h, ITS_EINVAL, std::string("bad value for option ") + name);
     }
     FAIL(h, ITS_EINVAL, std::string("unknown option ") + name);
 }
@@ -424,13 +433,13 @@ static int trip_cg(its_handle *h, double *res_out)
         if ((rc = finish_scalar(h, h->part[0], h->sc + SC_PQ, FIN_SUM))) return rc;
         pq = h->sc + SC_PQ; pq_scalar = 1;
     }
-    launch_cg_update_xr(h->x_a, h->r, h->p, h->tmp, n, pq, pq_scalar, rr_in, h->sc, h->part[1], h->stream);
+    launch_cg_update_r(h->r, h->tmp, n, pq, pq_scalar, rr_in, h->sc, h->part[1], h->stream);
     const double *rr = h->part[1]; int rr_scalar = 0;
     if (its_dist_active(h)) {
         if ((rc = finish_scalar(h, h->part[1], h->sc + SC_TMP, FIN_SUM))) return rc;
         rr = h->sc + SC_TMP; rr_scalar = 1;
     }
-    launch_cg_update_p(h->p, h->r, n, rr, rr_scalar, rr_in, rr_out, h->sc, res_out, h->stream);
+    launch_cg_update_xp(h->x_a, h->p, h->r, n, rr, rr_scalar, rr_in, rr_out, h->sc, res_out, h->stream);
     h->rr_slot ^= 1;
     HIPCHK(h, hipGetLastError());
     return ITS_OK;

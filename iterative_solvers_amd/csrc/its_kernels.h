@@ -60,6 +60,8 @@ struct SpmvArgs {
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 // same kernel over an explicit list of row-block descriptors (interior / boundary split of the
 // multi-GPU path); accumulate != 0 adds to the partials an earlier launch left
+// launch tunables of the exact SpMV: "spmv_grid", "spmv_map", "spmv_nt"; 0 ok, -1 bad value, -2 unknown name
+int spmv_tune(const char *name, int value);
 void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const SpmvArgs &a, int epilogue,
                             int accumulate, hipStream_t s);
 void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
@@ -82,16 +84,15 @@ void launch_fill(double *out, double v, int64_t n, hipStream_t s);
 // CG (methods/cg.hpp:40-281).  Device scalars live in a small double array `sc`:
 // ---------------------------------------------------------------------------------------
 enum { SC_RR0 = 0, SC_RR1 = 1, SC_PQ = 2, SC_ALPHA = 3, SC_BETA = 4, SC_RES = 5, SC_TMP = 6, SC_COUNT = 16 };
-// x += alpha p ; r -= alpha q ; part_rr = partial sum r^2.   alpha = rr_in[0] / (sum of part_pq)
-// If pq_is_scalar, part_pq[0] already holds the (all-reduced) sum.
-void launch_cg_update_xr(double *x, double *r, const double *p, const double *q, int64_t n,
-                         const double *part_pq, int pq_is_scalar, const double *rr_in, double *sc,
-                         double *part_rr, hipStream_t s);
-// p = r + beta p, beta = rr_new/rr_old[0] ; block 0 stores rr_new -> rr_new[0] (a different
-// slot than rr_old), sqrt(rr_new) -> res_out[0]
-void launch_cg_update_p(double *p, const double *r, int64_t n, const double *part_rr,
-                        int rr_is_scalar, const double *rr_old, double *rr_new, double *sc,
-                        double *res_out, hipStream_t s);
+// CG pass 1 (cg.hpp:162,182,186): alpha = rr_in[0] / sum(part_pq); r -= alpha q; part_rr[block] = partial r.r;
+// block 0 stores p.q and alpha in sc.  If pq_is_scalar, part_pq[0] already holds the (all-reduced) sum.
+void launch_cg_update_r(double *r, const double *q, int64_t n, const double *part_pq, int pq_is_scalar,
+                        const double *rr_in, double *sc, double *part_rr, hipStream_t s);
+// CG pass 2 (cg.hpp:181,188,202): beta = rr_new/rr_old[0]; x += sc[SC_ALPHA] p; p = r + beta p; block 0 stores
+// rr_new -> rr_new[0] (a different slot than rr_old), sqrt(rr_new) -> res_out[0]
+void launch_cg_update_xp(double *x, double *p, const double *r, int64_t n, const double *part_rr,
+                         int rr_is_scalar, const double *rr_old, double *rr_new, double *sc,
+                         double *res_out, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // GMRES modified Gram-Schmidt (methods/gmres.hpp:269-329,359,389) as fused axpy+dot steps.

@@ -3,6 +3,7 @@
 // (8 per CU on 256 CUs) walking their share of the work; HBM-bandwidth bound, no MFMA.
 #include "its_kernels.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace its {
 
@@ -122,7 +123,27 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream_kernel(
 constexpr int S2_CAP = SPMV_NNZ_MAX + 8;
 static_assert(SPMV_NNZ_MAX + 3 <= 2 * 4 * ITS_BLOCK, "staging is written for two slices of 4 entries per lane");
 
-template <int EPI, bool DOT>
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+// streaming loads: NT != 0 marks the col/val/row_ptr stream non-temporal so that it does not
+// push the gathered x window out of the XCD's L2
+template <int NT> __device__ __forceinline__ int4 ld_i4(const int *p)
+{
+    const v4i_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(p)) : *reinterpret_cast<const v4i_t *>(p);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+template <int NT> __device__ __forceinline__ double2 ld_d2(const double *p)
+{
+    const v2d_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p)) : *reinterpret_cast<const v2d_t *>(p);
+    return make_double2(v.x, v.y);
+}
+template <int NT> __device__ __forceinline__ int ld_i1(const int *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <int NT> __device__ __forceinline__ void st_d1(double *p, double v)
+{
+    if (NT & 2) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+template <int EPI, bool DOT, int NT>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
     int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
     const int *__restrict__ col, const double *__restrict__ val, int n_rows, SpmvArgs a)
@@ -160,16 +181,16 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         const int base_ = (d).z & ~3;                                                     \
         const int iA_ = base_ + 4 * t, iB_ = iA_ + 4 * ITS_BLOCK;                         \
         if (iA_ < (d).w) {                                                                \
-            rcA = *reinterpret_cast<const int4 *>(col + iA_);                             \
-            rvA0 = *reinterpret_cast<const double2 *>(val + iA_);                         \
-            rvA1 = *reinterpret_cast<const double2 *>(val + iA_ + 2);                     \
+            rcA = ld_i4<NT & 1>(col + iA_);                                               \
+            rvA0 = ld_d2<NT & 1>(val + iA_);                                              \
+            rvA1 = ld_d2<NT & 1>(val + iA_ + 2);                                          \
         }                                                                                 \
         if (iB_ < (d).w) {                                                                \
-            rcB = *reinterpret_cast<const int4 *>(col + iB_);                             \
-            rvB0 = *reinterpret_cast<const double2 *>(val + iB_);                         \
-            rvB1 = *reinterpret_cast<const double2 *>(val + iB_ + 2);                     \
+            rcB = ld_i4<NT & 1>(col + iB_);                                               \
+            rvB0 = ld_d2<NT & 1>(val + iB_);                                              \
+            rvB1 = ld_d2<NT & 1>(val + iB_ + 2);                                          \
         }                                                                                 \
-        if (t < (d).y) rrp = rp[(d).x + t];                                               \
+        if (t < (d).y) rrp = ld_i1<NT & 1>(rp + (d).x + t);                               \
     } while (0)
 #define S2_COMMIT(d, buf)                                                                 \
     do {                                                                                  \
@@ -193,12 +214,12 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
     bool have = false;
     int4 d = make_int4(0, 0, 0, 0), dn = d;
     if (niter > 0) {
-        d = blk_desc[rb0];
-        dn = blk_desc[min(rb0 + rstep, rb_last)];
+        d = blk_desc[rb0]; d.y &= 0xffff;
+        dn = blk_desc[min(rb0 + rstep, rb_last)]; dn.y &= 0xffff;
     }
     for (int it = 0; it < niter; ++it) {
         const int rb = rb0 + it * rstep;
-        const int4 dnn = blk_desc[min(rb + 2 * rstep, rb_last)];
+        int4 dnn = blk_desc[min(rb + 2 * rstep, rb_last)]; dnn.y &= 0xffff;
         const int rs = d.x, nr = d.y;
         const int row = rs + t;
         double acc = 0.0, diag = 0.0;
@@ -260,11 +281,11 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         }
         if (t < nr) {
             if (EPI == EPI_STORE) {
-                a.y[row] = acc;
+                st_d1<NT>(a.y + row, acc);
                 if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
             } else if (EPI == EPI_RESIDUAL) {
                 const double r = a.b[row] - acc;
-                a.y[row] = r;
+                st_d1<NT>(a.y + row, r);
                 lane_sum = fma(r, r, lane_sum);
                 lane_max = fmax(lane_max, fabs(r));
             } else if (EPI == EPI_JACOBI_SHIPPED) {
@@ -304,24 +325,279 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// v4 of the stream kernel: two row blocks of col/val/row_ptr in flight, gathers issued FIRST.
+//
+// gfx9 returns vector-memory operations in issue order (one vmcnt queue for loads and stores).
+// In v2 the x gathers are issued after the prefetch of the next row block, so the first fused
+// multiply-add waits for that whole prefetch, and the y store is the newest entry of the queue
+// when the next trip needs its staged registers: every trip pays prefetch latency + store
+// acknowledge with nothing else in flight.  Here each trip
+//   1. commits the register set that was issued TWO trips ago (long since complete),
+//   2. stores the previous trip's result, issues the epilogue loads, the LDS reads and the gathers,
+//   3. only then issues the loads of the row block two trips ahead — unconditionally (indices
+//      clamped to 0), as straight-line code, so that the waits in front of the multiply-adds can
+//      count them as "newer than the gathers" and leave them in flight,
+//   4. runs the in-order multiply-add chain and parks the result for step 2 of the next trip.
+// The loop is unrolled by two over the register sets P and Q (no register copies).  Rows longer
+// than 8 entries run their leading batches of 8 before step 2's final batch.  blk_desc[rb].y
+// carries rows | (longest row of the block << 16).
+// --------------------------------------------------------------------------------------
+struct StageRegs { int4 cA, cB; double2 vA0, vA1, vB0, vB1; int rp; };
+
+template <int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
+    int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
+    const int *__restrict__ col, const double *__restrict__ val, int n_rows, SpmvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double s_val[2][S2_CAP];
+    __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];
+    __shared__ int s_rp[2][ITS_BLOCK + 4];
+    __shared__ double s_red[4];
+
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    int rb0, rb1, rstep;
+    if (a.map_mode == 0) {
+        const int slot = xcd_slot(blockIdx.x, G);
+        rb0 = (int)(((int64_t)slot * nb) / G);
+        rb1 = (int)(((int64_t)(slot + 1) * nb) / G);
+        rstep = 1;
+    } else {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        const int X0 = (int)(((int64_t)xcd * nb) / 8), X1 = (int)(((int64_t)(xcd + 1) * nb) / 8);
+        rb0 = X0 + jx; rb1 = X1; rstep = G >> 3;
+    }
+    const int niter = rb0 < rb1 ? (rb1 - rb0 + rstep - 1) / rstep : 0;
+
+    double lane_sum = 0.0, lane_max = 0.0;
+    double pend_val = 0.0;
+    int pend_row = -1;
+
+#define S4_DESC(i) ((i) < niter ? blk_desc[rb0 + (i) * rstep] : make_int4(0, 0, 0, 0))
+    // all loads of one row block, unconditional: lanes past the end read entry 0
+#define S4_ISSUE(R, d)                                                                    \
+    do {                                                                                  \
+        const int base_ = (d).z & ~3;                                                     \
+        const int iA_ = base_ + 4 * t, iB_ = iA_ + 4 * ITS_BLOCK;                         \
+        const int jA_ = iA_ < (d).w ? iA_ : 0, jB_ = iB_ < (d).w ? iB_ : 0;               \
+        const int jr_ = t < ((d).y & 0xffff) ? (d).x + t : 0;                             \
+        R.cA = ld_i4<0>(col + jA_);                                                       \
+        R.vA0 = ld_d2<0>(val + jA_);                                                      \
+        R.vA1 = ld_d2<0>(val + jA_ + 2);                                                  \
+        R.cB = ld_i4<0>(col + jB_);                                                       \
+        R.vB0 = ld_d2<0>(val + jB_);                                                      \
+        R.vB1 = ld_d2<0>(val + jB_ + 2);                                                  \
+        R.rp = rp[jr_];                                                                   \
+    } while (0)
+#define S4_COMMIT(R, d, buf)                                                              \
+    do {                                                                                  \
+        const int base_ = (d).z & ~3;                                                     \
+        const int oA_ = 4 * t, oB_ = oA_ + 4 * ITS_BLOCK;                                 \
+        const int nr_ = (d).y & 0xffff;                                                   \
+        if (base_ + oA_ < (d).w) {                                                        \
+            *reinterpret_cast<int4 *>(&s_col[buf][oA_]) = R.cA;                           \
+            *reinterpret_cast<double2 *>(&s_val[buf][oA_]) = R.vA0;                       \
+            *reinterpret_cast<double2 *>(&s_val[buf][oA_ + 2]) = R.vA1;                   \
+        }                                                                                 \
+        if (base_ + oB_ < (d).w) {                                                        \
+            *reinterpret_cast<int4 *>(&s_col[buf][oB_]) = R.cB;                           \
+            *reinterpret_cast<double2 *>(&s_val[buf][oB_]) = R.vB0;                       \
+            *reinterpret_cast<double2 *>(&s_val[buf][oB_ + 2]) = R.vB1;                   \
+        }                                                                                 \
+        if (t < nr_) s_rp[buf][t] = R.rp;                                                 \
+        if (t == 0) s_rp[buf][nr_] = (d).w;                                               \
+    } while (0)
+    // one batch of 8 entries of this lane's row: LDS reads, then the x gathers (column 0 for
+    // slots past the end of the row: never a stale LDS word as an address)
+#define S4_BATCH_LOAD(buf)                                                                \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                       \
+        const bool ok_ = j + u < j1;                                                      \
+        const int jj_ = ok_ ? j + u : 0;                                                  \
+        const int cc_ = s_col[buf][jj_];                                                  \
+        c[u] = ok_ ? cc_ : 0; v[u] = s_val[buf][jj_];                                     \
+    }                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
+#define S4_BATCH_FMA()                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                       \
+        if (j + u < j1) {                                                                 \
+            if (EPI == EPI_JACOBI_REF && c[u] == row) diag = v[u];                        \
+            else acc = fma(v[u], xv[u], acc);                                             \
+        }                                                                                 \
+    }
+
+#define S4_BODY(R, buf)                                                                                   \
+    {                                                                                                     \
+        const int4 d = dA;                                                                                \
+        const int4 dD = S4_DESC(it + 3);                                                                  \
+        const int nr = d.y & 0xffff, nbat = (((d.y >> 16) + 7) >> 3);                                     \
+        const int row = d.x + t;                                                                          \
+        const bool lng = d.w - d.z > SPMV_NNZ_MAX;                                                        \
+        if (!lng) S4_COMMIT(R, d, buf);                                                                   \
+        __syncthreads();                                                                                  \
+        if (pend_row >= 0) { a.y[pend_row] = pend_val; pend_row = -1; }                                   \
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0;                                                              \
+        if (t < nr) {                                                                                     \
+            if (EPI == EPI_STORE && DOT) e0 = a.dotv[row];                                                \
+            if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS) e0 = a.b[row];         \
+            if (EPI == EPI_JACOBI_SHIPPED) { e0 = a.D[row]; e1 = a.x[row]; e2 = a.b[row]; }               \
+        }                                                                                                 \
+        double acc = 0.0, diag = 0.0;                                                                     \
+        int c[8]; double v[8], xv[8];                                                                     \
+        int j = 0, j1 = 0;                                                                                \
+        if (!lng) {                                                                                       \
+            if (t < nr) { const int base = d.z & ~3; j = s_rp[buf][t] - base; j1 = s_rp[buf][t + 1] - base; } \
+            _Pragma("unroll 1") for (int bb = 1; bb < nbat; ++bb) {                                       \
+                S4_BATCH_LOAD(buf) S4_BATCH_FMA() j += 8;                                                 \
+            }                                                                                             \
+            S4_BATCH_LOAD(buf)                                                                            \
+        } else {                                                                                          \
+            /* one row longer than the LDS capacity: stream it through the buffer in chunks, lane 0 */    \
+            /* keeps the in-order chain (rare: power-law tails) */                                        \
+            for (int c0 = d.z; c0 < d.w; c0 += SPMV_NNZ_MAX) {                                            \
+                const int c1 = min(d.w, c0 + SPMV_NNZ_MAX);                                               \
+                const int base = c0 & ~3;                                                                 \
+                __syncthreads();                                                                          \
+                for (int i = base + 4 * t; i < c1; i += 4 * ITS_BLOCK) {                                  \
+                    const int o = i - base;                                                               \
+                    *reinterpret_cast<int4 *>(&s_col[buf][o]) = *reinterpret_cast<const int4 *>(col + i); \
+                    *reinterpret_cast<double2 *>(&s_val[buf][o]) = *reinterpret_cast<const double2 *>(val + i); \
+                    *reinterpret_cast<double2 *>(&s_val[buf][o + 2]) = *reinterpret_cast<const double2 *>(val + i + 2); \
+                }                                                                                         \
+                __syncthreads();                                                                          \
+                if (t == 0) {                                                                             \
+                    for (int q = c0 - base; q < c1 - base; ++q) {                                         \
+                        const int cc = s_col[buf][q];                                                     \
+                        const double vv = s_val[buf][q];                                                  \
+                        if (EPI == EPI_JACOBI_REF && cc == row) diag = vv;                                \
+                        else acc = fma(vv, a.x[cc], acc);                                                 \
+                    }                                                                                     \
+                }                                                                                         \
+            }                                                                                             \
+            __syncthreads();                                                                              \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) { c[u] = 0; v[u] = 0.0; xv[u] = 0.0; }          \
+        }                                                                                                 \
+        S4_ISSUE(R, dC);                                                                                  \
+        S4_BATCH_FMA()                                                                                    \
+        if (t < nr) {                                                                                     \
+            double outv;                                                                                  \
+            if (EPI == EPI_STORE) {                                                                       \
+                outv = acc;                                                                               \
+                if (DOT) lane_sum = fma(acc, e0, lane_sum);                                               \
+            } else if (EPI == EPI_RESIDUAL) {                                                             \
+                outv = e0 - acc;                                                                          \
+                lane_sum = fma(outv, outv, lane_sum);                                                     \
+                lane_max = fmax(lane_max, fabs(outv));                                                    \
+            } else if (EPI == EPI_JACOBI_SHIPPED) {                                                       \
+                const double adj = fma(-e0, acc, e1);                                                     \
+                outv = (e2 - adj) / e0;                                                                   \
+            } else if (EPI == EPI_JACOBI_REF) {                                                           \
+                outv = (e0 - acc) / diag;                                                                 \
+            } else {                                                                                      \
+                outv = fma(-1.0, acc, e0);                                                                \
+            }                                                                                             \
+            pend_val = outv; pend_row = row;                                                              \
+        }                                                                                                 \
+        dA = dB; dB = dC; dC = dD;                                                                        \
+        ++it;                                                                                             \
+    }
+
+    if (niter > 0) {
+        StageRegs P, Q;
+        int4 dA = S4_DESC(0), dB = S4_DESC(1), dC = S4_DESC(2);
+        S4_ISSUE(P, dA);
+        S4_ISSUE(Q, dB);
+        const int niter2 = (niter + 1) & ~1;
+        int it = 0;
+        while (it < niter2) {
+            S4_BODY(P, 0)
+            S4_BODY(Q, 1)
+        }
+        if (pend_row >= 0) a.y[pend_row] = pend_val;
+    }
+#undef S4_DESC
+#undef S4_ISSUE
+#undef S4_COMMIT
+#undef S4_BATCH_LOAD
+#undef S4_BATCH_FMA
+#undef S4_BODY
+    if (DOT || EPI == EPI_RESIDUAL) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) {
+            if (a.part_accum) a.part_sum[blockIdx.x] += bs;
+            else {
+                a.part_sum[blockIdx.x] = bs;
+                for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
+            }
+        }
+        if (EPI == EPI_RESIDUAL && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) {
+                if (a.part_accum) a.part_max[blockIdx.x] = fmax(a.part_max[blockIdx.x], bm);
+                else {
+                    a.part_max[blockIdx.x] = bm;
+                    for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_max[z] = 0.0;
+                }
+            }
+        }
+    }
+}
+
 static int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
 
+// launch tunables of the exact SpMV (its_set_option "spmv_grid" / "spmv_map" / "spmv_nt")
+// defaults measured on MI355X, 256^3 7-pt: v4 with 2 workgroups per CU (0.369 ms) vs v2 with 4 (0.376 ms)
+static int g_spmv_variant = env_int("ITS_SPMV_VARIANT", 4);
+static int g_spmv_grid = env_int("ITS_SPMV_GRID", g_spmv_variant == 4 ? 512 : 1024);
+static int g_spmv_map = env_int("ITS_SPMV_MAP", 1);
+static int g_spmv_nt = env_int("ITS_SPMV_NT", 0);
+int spmv_tune(const char *name, int value)
+{
+    if (!strcmp(name, "spmv_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_grid = value; return 0; }
+    if (!strcmp(name, "spmv_map")) { if (value < 0 || value > 1) return -1; g_spmv_map = value; return 0; }
+    if (!strcmp(name, "spmv_variant")) { if (value != 1 && value != 2 && value != 4) return -1; g_spmv_variant = value; return 0; }
+    if (!strcmp(name, "spmv_nt")) { if (value < 0 || value > 3) return -1; g_spmv_nt = value; return 0; }
+    return -2;
+}
+
 void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const SpmvArgs &a_in, int epi,
                             int accumulate, hipStream_t s)
 {
-    static int g2v = env_int("ITS_SPMV_GRID", 1024);
-    static const int mm = env_int("ITS_SPMV_MAP", 1);
+    int g2v = g_spmv_grid;
+    const int mm = g_spmv_map;
     if (g2v < 8 || g2v > ITS_NPART || (g2v & 7)) g2v = 1024;
     dim3 g2(g2v), b(ITS_BLOCK);
     SpmvArgs a = a_in;
     a.map_mode = mm;
     a.part_accum = accumulate;
-#define ITS_LAUNCH2(E, D) \
-    hipLaunchKernelGGL((spmv_stream2_kernel<E, D>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
+#define ITS_LAUNCH2N(E, D, N) \
+    hipLaunchKernelGGL((spmv_stream2_kernel<E, D, N>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
+#define ITS_LAUNCH2(E, D)                                                          \
+    do {                                                                           \
+        switch (g_spmv_nt) {                                                       \
+        case 1: ITS_LAUNCH2N(E, D, 1); break;                                      \
+        case 2: ITS_LAUNCH2N(E, D, 2); break;                                      \
+        case 3: ITS_LAUNCH2N(E, D, 3); break;                                      \
+        default: ITS_LAUNCH2N(E, D, 0); break;                                     \
+        }                                                                          \
+    } while (0)
+#define ITS_LAUNCH4(E, D) \
+    hipLaunchKernelGGL((spmv_stream4_kernel<E, D>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
+    if (g_spmv_variant == 4) {
+        switch (epi) {
+        case EPI_STORE: if (a.dotv) ITS_LAUNCH4(EPI_STORE, true); else ITS_LAUNCH4(EPI_STORE, false); break;
+        case EPI_RESIDUAL: ITS_LAUNCH4(EPI_RESIDUAL, false); break;
+        case EPI_JACOBI_SHIPPED: ITS_LAUNCH4(EPI_JACOBI_SHIPPED, false); break;
+        case EPI_JACOBI_REF: ITS_LAUNCH4(EPI_JACOBI_REF, false); break;
+        case EPI_GS_RHS: ITS_LAUNCH4(EPI_GS_RHS, false); break;
+        }
+        return;
+    }
+#undef ITS_LAUNCH4
     switch (epi) {
     case EPI_STORE: if (a.dotv) ITS_LAUNCH2(EPI_STORE, true); else ITS_LAUNCH2(EPI_STORE, false); break;
     case EPI_RESIDUAL: ITS_LAUNCH2(EPI_RESIDUAL, false); break;
@@ -330,13 +606,14 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
     case EPI_GS_RHS: ITS_LAUNCH2(EPI_GS_RHS, false); break;
     }
 #undef ITS_LAUNCH2
+#undef ITS_LAUNCH2N
 }
 
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
 {
-    static const int variant = env_int("ITS_SPMV_VARIANT", 2);
+    const int variant = g_spmv_variant;
     dim3 b(ITS_BLOCK);
-    if (variant == 2) { launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s); return; }
+    if (variant != 1) { launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s); return; }
     const SpmvArgs &a = a_in;
     dim3 g(ITS_NPART);
 #define ITS_LAUNCH(E, D) \
@@ -595,10 +872,12 @@ void launch_fill(double *out, double v, int64_t n, hipStream_t s)
 // ======================================================================================
 // CG vector updates (methods/cg.hpp:204-230) with the reductions fused in.
 // ======================================================================================
-__global__ __launch_bounds__(ITS_BLOCK) void cg_update_xr_kernel(
-    double *__restrict__ x, double *__restrict__ r, const double *__restrict__ p,
-    const double *__restrict__ q, int64_t n, const double *__restrict__ part_pq, int pq_is_scalar,
-    const double *__restrict__ rr_in, double *__restrict__ sc, double *__restrict__ part_rr)
+// Pass 1 of a CG trip: alpha = rr / (p.q); r -= alpha q; partial sums of r.r.  (x += alpha p needs p
+// once more and moves into pass 2, which reads p anyway: 64n bytes per trip instead of 72n; the
+// per-element operations and their order are those of cg.hpp:181-202, so the bits are unchanged.)
+__global__ __launch_bounds__(ITS_BLOCK) void cg_update_r_kernel(
+    double *__restrict__ r, const double *__restrict__ q, int64_t n, const double *__restrict__ part_pq,
+    int pq_is_scalar, const double *__restrict__ rr_in, double *__restrict__ sc, double *__restrict__ part_rr)
 {
     __shared__ double s_red[4];
     const double pq = pq_is_scalar ? part_pq[0] : sum_partials(part_pq, s_red);
@@ -607,18 +886,16 @@ __global__ __launch_bounds__(ITS_BLOCK) void cg_update_xr_kernel(
     const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
     double s0 = 0.0, s1 = 0.0;
     const int64_t n2 = n / 2;                                  // solver vectors are 256-byte aligned
-    double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
-    const double2 *p2 = reinterpret_cast<const double2 *>(p), *q2 = reinterpret_cast<const double2 *>(q);
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *q2 = reinterpret_cast<const double2 *>(q);
     for (int64_t i = tid; i < n2; i += nth) {
-        double2 xv = x2[i], rv = r2[i];
-        const double2 pv = p2[i], qv = q2[i];
-        xv.x = fma(alpha, pv.x, xv.x); xv.y = fma(alpha, pv.y, xv.y);      // cg.hpp:181
+        double2 rv = r2[i];
+        const double2 qv = q2[i];
         rv.x = fma(-alpha, qv.x, rv.x); rv.y = fma(-alpha, qv.y, rv.y);    // cg.hpp:182
-        x2[i] = xv; r2[i] = rv;
+        r2[i] = rv;
         s0 = fma(rv.x, rv.x, s0); s1 = fma(rv.y, rv.y, s1);                // cg.hpp:186
     }
     for (int64_t i = 2 * n2 + tid; i < n; i += nth) {
-        x[i] = fma(alpha, p[i], x[i]);
         const double rv = fma(-alpha, q[i], r[i]);
         r[i] = rv;
         s0 = fma(rv, rv, s0);
@@ -630,8 +907,9 @@ __global__ __launch_bounds__(ITS_BLOCK) void cg_update_xr_kernel(
     }
 }
 
-__global__ __launch_bounds__(ITS_BLOCK) void cg_update_p_kernel(
-    double *__restrict__ p, const double *__restrict__ r, int64_t n,
+// Pass 2: beta = rr_new / rr_old; x += alpha p (alpha from pass 1, sc[SC_ALPHA]); p = r + beta p.
+__global__ __launch_bounds__(ITS_BLOCK) void cg_update_xp_kernel(
+    double *__restrict__ x, double *__restrict__ p, const double *__restrict__ r, int64_t n,
     const double *__restrict__ part_rr, int rr_is_scalar, const double *__restrict__ rr_old_p,
     double *__restrict__ rr_new_p, double *__restrict__ sc, double *__restrict__ res_out)
 {
@@ -639,34 +917,39 @@ __global__ __launch_bounds__(ITS_BLOCK) void cg_update_p_kernel(
     const double rr_new = rr_is_scalar ? part_rr[0] : sum_partials(part_rr, s_red);
     const double rr_old = rr_old_p[0];
     const double beta = rr_new / rr_old;                       // cg.hpp:188
+    const double alpha = sc[SC_ALPHA];
     const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
     const int64_t n2 = n / 2;
-    double2 *p2 = reinterpret_cast<double2 *>(p);
+    double2 *p2 = reinterpret_cast<double2 *>(p), *x2 = reinterpret_cast<double2 *>(x);
     const double2 *r2 = reinterpret_cast<const double2 *>(r);
     for (int64_t i = tid; i < n2; i += nth) {
-        double2 pv = p2[i];
+        double2 pv = p2[i], xv = x2[i];
         const double2 rv = r2[i];
+        xv.x = fma(alpha, pv.x, xv.x); xv.y = fma(alpha, pv.y, xv.y);      // cg.hpp:181
         pv.x = fma(beta, pv.x, rv.x); pv.y = fma(beta, pv.y, rv.y);        // cg.hpp:202
-        p2[i] = pv;
+        x2[i] = xv; p2[i] = pv;
     }
-    for (int64_t i = 2 * n2 + tid; i < n; i += nth) p[i] = fma(beta, p[i], r[i]);
+    for (int64_t i = 2 * n2 + tid; i < n; i += nth) {
+        const double pv = p[i];
+        x[i] = fma(alpha, pv, x[i]);
+        p[i] = fma(beta, pv, r[i]);
+    }
     // rr_new goes to the OTHER rr slot (rr_new_p != rr_old_p): other workgroups may still be
-    // reading rr_old.
+    // reading rr_old.  sc[SC_ALPHA] is only rewritten by the next trip's pass 1 (a later kernel).
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         rr_new_p[0] = rr_new; sc[SC_BETA] = beta;
         if (res_out) res_out[0] = sqrt(rr_new);                // utility_funcs.hpp:483
     }
 }
 
-void launch_cg_update_xr(double *x, double *r, const double *p, const double *q, int64_t n,
-                         const double *part_pq, int pq_is_scalar, const double *rr_in, double *sc,
-                         double *part_rr, hipStream_t s)
-{ hipLaunchKernelGGL(cg_update_xr_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, x, r, p, q, n, part_pq, pq_is_scalar, rr_in, sc, part_rr); }
+void launch_cg_update_r(double *r, const double *q, int64_t n, const double *part_pq, int pq_is_scalar,
+                        const double *rr_in, double *sc, double *part_rr, hipStream_t s)
+{ hipLaunchKernelGGL(cg_update_r_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, r, q, n, part_pq, pq_is_scalar, rr_in, sc, part_rr); }
 
-void launch_cg_update_p(double *p, const double *r, int64_t n, const double *part_rr, int rr_is_scalar,
-                        const double *rr_old, double *rr_new, double *sc, double *res_out, hipStream_t s)
-{ hipLaunchKernelGGL(cg_update_p_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, p, r, n, part_rr, rr_is_scalar, rr_old, rr_new, sc, res_out); }
+void launch_cg_update_xp(double *x, double *p, const double *r, int64_t n, const double *part_rr, int rr_is_scalar,
+                         const double *rr_old, double *rr_new, double *sc, double *res_out, hipStream_t s)
+{ hipLaunchKernelGGL(cg_update_xp_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, x, p, r, n, part_rr, rr_is_scalar, rr_old, rr_new, sc, res_out); }
 
 // ======================================================================================
 // GMRES: modified Gram-Schmidt as fused "finish previous axpy + start next dot" steps.
