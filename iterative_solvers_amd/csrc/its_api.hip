@@ -181,6 +181,8 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     if (dalloc(h, &A.blk_desc, desc.size())) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.blk_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
     A.lanes_per_row = pick_lanes_per_row(n_rows, nnz);
+    A.max_row_len = 0;
+    for (int i = 0; i < n_rows; ++i) A.max_row_len = std::max(A.max_row_len, row_ptr[i + 1] - row_ptr[i]);
     if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; }
     h->have[which] = true;
     if (which == ITS_MAT_A) { h->fmt = format; h->setup_done = false; h->residual_done = false; }

@@ -12,7 +12,8 @@ namespace its {
 // SPMV_NNZ_MAX nonzeros (a single longer row forms a block of its own and is walked in
 // several LDS chunks).  blk_row[nb+1] holds the first row of each block.
 // ---------------------------------------------------------------------------------------
-constexpr int SPMV_NNZ_MAX = 1536;      // (1536+8)*(8+4) B + row ptrs ≈ 19.6 KB LDS per buffer
+constexpr int SPMV_NNZ_MAX = 1536;
+constexpr int IRR_ROW_LEN = 32;           // longest row above which the exact SpMV splits gather and arithmetic      // (1536+8)*(8+4) B + row ptrs ≈ 19.6 KB LDS per buffer
 // col/val are allocated with this many zero elements after nnz: the stream kernel's prefetch
 // loads are unconditional (2 slices x 1024 entries past an aligned block start)
 constexpr int CSR_PAD = 2048 + 16;
@@ -36,6 +37,7 @@ struct CsrDev {
     int4 *blk_desc = nullptr;                 // {first row, rows, first nnz, end nnz} per row block
     // vector-CSR plan
     int lanes_per_row = 0;
+    int max_row_len = 0;                      // longest row: > IRR_ROW_LEN selects the irregular-row exact kernel
     // SELL-64-sigma image
     int sell_chunks = 0, sell_sigma = 0;
     int64_t sell_elems = 0;

@@ -543,6 +543,164 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// Exact SpMV for IRREGULAR row lengths (power-law matrices): gather and arithmetic are split.
+//   phase A: all 256 lanes stream the row block's col/val slice (16 B per lane, coalesced) and
+//            gather x[col] for the entries THEY loaded — perfectly parallel whatever the rows
+//            look like — and park val, x[col] (and col) in LDS;
+//   phase B: one lane per row runs the in-order multiply-add chain out of LDS only, so a long
+//            row costs LDS latency per entry, not a memory round trip per 8 entries.
+// Same arithmetic as spmv_crs_cpu (kernels.hpp:380-409): bit-exact.  The next row block's slice
+// is prefetched into registers before phase B.  Chosen at launch when the matrix's longest row
+// exceeds IRR_ROW_LEN (CsrDev::max_row_len); rows longer than the LDS capacity are streamed in
+// chunks with lane 0 carrying the chain across chunks.
+// --------------------------------------------------------------------------------------
+template <int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_irr_kernel(
+    int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
+    const int *__restrict__ col, const double *__restrict__ val, int n_rows, SpmvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double s_val[S2_CAP];
+    __shared__ __attribute__((aligned(16))) double s_xg[S2_CAP];
+    __shared__ __attribute__((aligned(16))) int s_col[S2_CAP];
+    __shared__ int s_rp[ITS_BLOCK + 4];
+    __shared__ double s_red[4];
+
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    int rb0, rb1, rstep;
+    if (a.map_mode == 0) {
+        const int slot = xcd_slot(blockIdx.x, G);
+        rb0 = (int)(((int64_t)slot * nb) / G);
+        rb1 = (int)(((int64_t)(slot + 1) * nb) / G);
+        rstep = 1;
+    } else {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        const int X0 = (int)(((int64_t)xcd * nb) / 8), X1 = (int)(((int64_t)(xcd + 1) * nb) / 8);
+        rb0 = X0 + jx; rb1 = X1; rstep = G >> 3;
+    }
+    double lane_sum = 0.0, lane_max = 0.0;
+
+    // staging registers of the slice in flight (two sub-slices of 4 entries per lane)
+    int4 rcA = make_int4(0, 0, 0, 0), rcB = rcA;
+    double2 rvA0 = make_double2(0, 0), rvA1 = rvA0, rvB0 = rvA0, rvB1 = rvA0;
+    bool have = false;
+
+#define IRR_ISSUE(c1v, basev)                                                             \
+    do {                                                                                  \
+        const int iA_ = (basev) + 4 * t, iB_ = iA_ + 4 * ITS_BLOCK;                       \
+        if (iA_ < (c1v)) {                                                                \
+            rcA = ld_i4<0>(col + iA_); rvA0 = ld_d2<0>(val + iA_); rvA1 = ld_d2<0>(val + iA_ + 2); \
+        }                                                                                 \
+        if (iB_ < (c1v)) {                                                                \
+            rcB = ld_i4<0>(col + iB_); rvB0 = ld_d2<0>(val + iB_); rvB1 = ld_d2<0>(val + iB_ + 2); \
+        }                                                                                 \
+    } while (0)
+    // gather x for the staged entries and park everything in LDS.  Staged columns are real matrix
+    // columns or the zero padding behind the arrays, so every gather address is inside x.
+#define IRR_PARK(c1v, basev)                                                              \
+    do {                                                                                  \
+        const int oA_ = 4 * t, oB_ = oA_ + 4 * ITS_BLOCK;                                 \
+        const bool okA_ = (basev) + oA_ < (c1v), okB_ = (basev) + oB_ < (c1v);            \
+        double gA0 = 0, gA1 = 0, gA2 = 0, gA3 = 0, gB0 = 0, gB1 = 0, gB2 = 0, gB3 = 0;    \
+        if (okA_) { gA0 = a.x[rcA.x]; gA1 = a.x[rcA.y]; gA2 = a.x[rcA.z]; gA3 = a.x[rcA.w]; } \
+        if (okB_) { gB0 = a.x[rcB.x]; gB1 = a.x[rcB.y]; gB2 = a.x[rcB.z]; gB3 = a.x[rcB.w]; } \
+        if (okA_) {                                                                       \
+            *reinterpret_cast<int4 *>(&s_col[oA_]) = rcA;                                 \
+            *reinterpret_cast<double2 *>(&s_val[oA_]) = rvA0;                             \
+            *reinterpret_cast<double2 *>(&s_val[oA_ + 2]) = rvA1;                         \
+            *reinterpret_cast<double2 *>(&s_xg[oA_]) = make_double2(gA0, gA1);            \
+            *reinterpret_cast<double2 *>(&s_xg[oA_ + 2]) = make_double2(gA2, gA3);        \
+        }                                                                                 \
+        if (okB_) {                                                                       \
+            *reinterpret_cast<int4 *>(&s_col[oB_]) = rcB;                                 \
+            *reinterpret_cast<double2 *>(&s_val[oB_]) = rvB0;                             \
+            *reinterpret_cast<double2 *>(&s_val[oB_ + 2]) = rvB1;                         \
+            *reinterpret_cast<double2 *>(&s_xg[oB_]) = make_double2(gB0, gB1);            \
+            *reinterpret_cast<double2 *>(&s_xg[oB_ + 2]) = make_double2(gB2, gB3);        \
+        }                                                                                 \
+    } while (0)
+#define IRR_CHAIN(jb, je)                                                                 \
+    for (int j = (jb); j < (je); ++j) {                                                   \
+        const double vv = s_val[j];                                                       \
+        if (EPI == EPI_JACOBI_REF && s_col[j] == row) diag = vv;                          \
+        else acc = fma(vv, s_xg[j], acc);                                                 \
+    }
+
+    for (int rb = rb0; rb < rb1; rb += rstep) {
+        const int4 d = blk_desc[rb];
+        const int nr = d.y & 0xffff;
+        const int row = d.x + t;
+        const int rbn = rb + rstep;
+        int4 dn = make_int4(0, 0, 0, 0);
+        if (rbn < rb1) dn = blk_desc[rbn];
+        double acc = 0.0, diag = 0.0;
+        int my_rp = 0;
+        if (t < nr) my_rp = rp[d.x + t];
+        for (int c0 = d.z; ; c0 += SPMV_NNZ_MAX) {
+            const int c1 = min(d.w, c0 + SPMV_NNZ_MAX);
+            const int base = c0 & ~3;
+            if (!have) IRR_ISSUE(c1, base);
+            have = false;
+            __syncthreads();                       // phase B of the previous chunk / block is done with LDS
+            IRR_PARK(c1, base);
+            if (c0 == d.z) { if (t < nr) s_rp[t] = my_rp; if (t == 0) s_rp[nr] = d.w; }
+            __syncthreads();
+            // prefetch: the next chunk of this long row, else the first chunk of the next row block
+            if (c1 < d.w) { IRR_ISSUE(min(d.w, c1 + SPMV_NNZ_MAX), c1 & ~3); have = true; }
+            else if (rbn < rb1) { IRR_ISSUE(min(dn.w, dn.z + SPMV_NNZ_MAX), dn.z & ~3); have = true; }
+            if (d.w - d.z <= SPMV_NNZ_MAX) {
+                if (t < nr) { IRR_CHAIN(s_rp[t] - base, s_rp[t + 1] - base) }
+            } else if (t == 0) {
+                IRR_CHAIN(c0 - base, c1 - base)
+            }
+            if (c1 >= d.w) break;
+        }
+        if (t < nr) {
+            if (EPI == EPI_STORE) {
+                a.y[row] = acc;
+                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
+            } else if (EPI == EPI_RESIDUAL) {
+                const double r = a.b[row] - acc;
+                a.y[row] = r;
+                lane_sum = fma(r, r, lane_sum);
+                lane_max = fmax(lane_max, fabs(r));
+            } else if (EPI == EPI_JACOBI_SHIPPED) {
+                const double dd = a.D[row];
+                const double adj = fma(-dd, acc, a.x[row]);
+                a.y[row] = (a.b[row] - adj) / dd;
+            } else if (EPI == EPI_JACOBI_REF) {
+                a.y[row] = (a.b[row] - acc) / diag;
+            } else if (EPI == EPI_GS_RHS) {
+                a.y[row] = fma(-1.0, acc, a.b[row]);
+            }
+        }
+    }
+#undef IRR_ISSUE
+#undef IRR_PARK
+#undef IRR_CHAIN
+    if (DOT || EPI == EPI_RESIDUAL) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) {
+            if (a.part_accum) a.part_sum[blockIdx.x] += bs;
+            else {
+                a.part_sum[blockIdx.x] = bs;
+                for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
+            }
+        }
+        if (EPI == EPI_RESIDUAL && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) {
+                if (a.part_accum) a.part_max[blockIdx.x] = fmax(a.part_max[blockIdx.x], bm);
+                else {
+                    a.part_max[blockIdx.x] = bm;
+                    for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_max[z] = 0.0;
+                }
+            }
+        }
+    }
+}
+
 static int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
@@ -554,12 +712,16 @@ static int env_int(const char *name, int dflt)
 static int g_spmv_variant = env_int("ITS_SPMV_VARIANT", 4);
 static int g_spmv_grid = env_int("ITS_SPMV_GRID", g_spmv_variant == 4 ? 512 : 1024);
 static int g_spmv_map = env_int("ITS_SPMV_MAP", 1);
+static int g_spmv_irr = env_int("ITS_SPMV_IRR", 1);             // 0 = never use the irregular-row kernel
+static int g_spmv_irr_grid = env_int("ITS_SPMV_IRR_GRID", 1280);
 static int g_spmv_nt = env_int("ITS_SPMV_NT", 0);
 int spmv_tune(const char *name, int value)
 {
     if (!strcmp(name, "spmv_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_grid = value; return 0; }
     if (!strcmp(name, "spmv_map")) { if (value < 0 || value > 1) return -1; g_spmv_map = value; return 0; }
     if (!strcmp(name, "spmv_variant")) { if (value != 1 && value != 2 && value != 4) return -1; g_spmv_variant = value; return 0; }
+    if (!strcmp(name, "spmv_irr")) { if (value < 0 || value > 1) return -1; g_spmv_irr = value; return 0; }
+    if (!strcmp(name, "spmv_irr_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_irr_grid = value; return 0; }
     if (!strcmp(name, "spmv_nt")) { if (value < 0 || value > 3) return -1; g_spmv_nt = value; return 0; }
     return -2;
 }
@@ -585,6 +747,21 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
         default: ITS_LAUNCH2N(E, D, 0); break;                                     \
         }                                                                          \
     } while (0)
+    // irregular rows: the two-phase kernel (5 workgroups per CU by its LDS footprint)
+    if (A.max_row_len > IRR_ROW_LEN && g_spmv_variant != 1 && g_spmv_irr) {
+        dim3 gi(g_spmv_irr_grid);
+#define ITS_LAUNCHI(E, D) \
+    hipLaunchKernelGGL((spmv_irr_kernel<E, D>), gi, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
+        switch (epi) {
+        case EPI_STORE: if (a.dotv) ITS_LAUNCHI(EPI_STORE, true); else ITS_LAUNCHI(EPI_STORE, false); break;
+        case EPI_RESIDUAL: ITS_LAUNCHI(EPI_RESIDUAL, false); break;
+        case EPI_JACOBI_SHIPPED: ITS_LAUNCHI(EPI_JACOBI_SHIPPED, false); break;
+        case EPI_JACOBI_REF: ITS_LAUNCHI(EPI_JACOBI_REF, false); break;
+        case EPI_GS_RHS: ITS_LAUNCHI(EPI_GS_RHS, false); break;
+        }
+#undef ITS_LAUNCHI
+        return;
+    }
 #define ITS_LAUNCH4(E, D) \
     hipLaunchKernelGGL((spmv_stream4_kernel<E, D>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
     if (g_spmv_variant == 4) {

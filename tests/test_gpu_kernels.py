@@ -52,6 +52,21 @@ def test_spmv_ragged(gpu_handle, n, max_len, empty_every, long_rows):
         assert np.all(np.abs(got[fmt] - ref) <= 1e-12 * np.maximum(absrow, scale * 1e-3))
 
 
+def test_spmv_both_exact_kernels(gpu_handle):
+    """Regular (v4 stream) and irregular (two-phase) exact kernels on the same ragged matrix: both bit-exact."""
+    rp, col, val = random_crs(3000, 12, seed=11, long_rows=((5, 1792), (100, 9000), (2999, 40)))
+    n = len(rp) - 1
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    ref = orc.spmv(rp, col, val, x)
+    try:
+        for irr in (0, 1):
+            gpu_handle.set_option("spmv_irr", irr)
+            gpu_handle.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+            assert np.array_equal(gpu_handle.spmv_host(x, n, capi.MAT_A, capi.FMT_CSR_EXACT), ref), irr
+    finally:
+        gpu_handle.set_option("spmv_irr", 1)
+
+
 def test_spmv_known_answers(gpu_handle):
     """M1*V1 = {74,134,194}, Mn*V1 = {-58,-22,-76.2} (reference test_suite/test_data.cpp:40-49,4-13,467-494)."""
     import json, os
