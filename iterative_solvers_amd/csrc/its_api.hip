@@ -15,7 +15,7 @@
 static void free_csr(CsrDev &A)
 {
     dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_row); dfree(A.blk_desc);
-    dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val);
+    dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start);
     A = CsrDev();
 }
 
@@ -98,27 +98,55 @@ static int build_sell(its_handle *h, CsrDev &A, int n, const int *rp, const int 
 {
     const int C = 64;
     int sigma = 4096;
-    if (const char *e = getenv("ITS_SELL_SIGMA")) sigma = std::max(1, atoi(e));
+    bool sigma_fixed = false;
+    if (const char *e = getenv("ITS_SELL_SIGMA")) { sigma = std::max(1, atoi(e)); sigma_fixed = true; }
     const int n_chunks = (n + C - 1) / C, n_pad = n_chunks * C;
+    const int64_t nnz = n > 0 ? rp[n] : 0;
     std::vector<int> order(n_pad);
-    std::iota(order.begin(), order.end(), 0);
     auto len = [&](int r) { return r < n ? rp[r + 1] - rp[r] : 0; };
-    if (sigma > 1)
-        for (int i = 0; i < n_pad; i += sigma)
-            std::stable_sort(order.begin() + i, order.begin() + std::min(n_pad, i + sigma),
-                             [&](int a, int b) { return len(a) > len(b); });
     std::vector<int> cptr(n_chunks + 1), clen(n_chunks), perm(n_pad);
     int64_t tot = 0;
-    for (int c = 0; c < n_chunks; ++c) {
-        int mx = 0;
-        for (int r = 0; r < C; ++r) mx = std::max(mx, len(order[c * C + r]));
-        clen[c] = mx;
-        if (tot > INT32_MAX) FAIL(h, ITS_EUNSUPPORTED, "SELL image exceeds int32 offsets");
-        cptr[c] = (int)tot;
-        tot += (int64_t)mx * C;
+    // sigma grows (x8) while less than 60 % of the stored elements are real: power-law rows need a
+    // wide sorting window before chunks of 64 rows have similar lengths
+    for (;;) {
+        std::iota(order.begin(), order.end(), 0);
+        if (sigma > 1)
+            for (int i = 0; i < n_pad; i += sigma)
+                std::stable_sort(order.begin() + i, order.begin() + std::min(n_pad, i + sigma),
+                                 [&](int a, int b) { return len(a) > len(b); });
+        tot = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            int mx = 0;
+            for (int r = 0; r < C; ++r) mx = std::max(mx, len(order[c * C + r]));
+            clen[c] = mx;
+            tot += (int64_t)mx * C;
+        }
+        if (sigma_fixed || sigma >= n_pad || tot == 0 || (double)nnz / (double)tot >= 0.6) break;
+        sigma = (int)std::min<int64_t>((int64_t)sigma * 8, n_pad);
     }
     if (tot > INT32_MAX) FAIL(h, ITS_EUNSUPPORTED, "SELL image exceeds int32 offsets");
+    tot = 0;
+    for (int c = 0; c < n_chunks; ++c) { cptr[c] = (int)tot; tot += (int64_t)clen[c] * C; }
     cptr[n_chunks] = (int)tot;
+    // work-balanced static partition: groups of 4 chunks (one per wave) dealt to ITS_NPART workgroup
+    // slots so that every slot gets about the same number of stored elements (+ a per-group constant)
+    const int n_grp = (n_chunks + 3) / 4;
+    std::vector<int> gstart(ITS_NPART + 1, n_grp);
+    {
+        std::vector<int64_t> pre(n_grp + 1, 0);
+        for (int g = 0; g < n_grp; ++g) {
+            int64_t wk = 16;
+            for (int c = 4 * g; c < std::min(n_chunks, 4 * g + 4); ++c) wk += clen[c];
+            pre[g + 1] = pre[g] + wk;
+        }
+        int g = 0;
+        for (int sl = 0; sl <= ITS_NPART; ++sl) {
+            const int64_t target = pre[n_grp] * sl / ITS_NPART;
+            while (g < n_grp && pre[g] < target) ++g;
+            gstart[sl] = g;
+        }
+        gstart[0] = 0; gstart[ITS_NPART] = n_grp;
+    }
     std::vector<int> scol((size_t)tot, 0);
     std::vector<double> sval((size_t)tot, 0.0);
     for (int c = 0; c < n_chunks; ++c)
@@ -132,6 +160,8 @@ static int build_sell(its_handle *h, CsrDev &A, int n, const int *rp, const int 
             }
         }
     A.sell_chunks = n_chunks; A.sell_sigma = sigma; A.sell_elems = tot;
+    if (dalloc(h, &A.sell_grp_start, gstart.size())) return ITS_EHIP;
+    HIPCHK(h, hipMemcpy(A.sell_grp_start, gstart.data(), gstart.size() * sizeof(int), hipMemcpyHostToDevice));
     if (dalloc(h, &A.sell_chunk_ptr, n_chunks + 1) || dalloc(h, &A.sell_chunk_len, n_chunks) ||
         dalloc(h, &A.sell_perm, n_pad) || dalloc(h, &A.sell_col, (size_t)tot) || dalloc(h, &A.sell_val, (size_t)tot))
         return ITS_EHIP;
@@ -326,7 +356,10 @@ static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc)
     for (int i = 0; i < n; ++i) ++h->level_ptr[lev[i] + 1];
     for (int l = 0; l < nl; ++l) h->level_ptr[l + 1] += h->level_ptr[l];
     std::vector<int> rows(n), fill(h->level_ptr.begin(), h->level_ptr.end() - (nl ? 1 : 0));
-    for (int i = 0; i < n; ++i) rows[fill[lev[i]]++] = i;            // ascending row inside a level
+    // inside a level: short rows first (one lane each), then the long ones (one wave each), both ascending
+    h->level_nshort.assign(nl, 0);
+    for (int i = 0; i < n; ++i) if (Lp[i + 1] - Lp[i] <= SWEEP_SHORT) { rows[fill[lev[i]]++] = i; ++h->level_nshort[lev[i]]; }
+    for (int i = 0; i < n; ++i) if (Lp[i + 1] - Lp[i] > SWEEP_SHORT) rows[fill[lev[i]]++] = i;
     dfree(h->level_rows);
     if (dalloc(h, &h->level_rows, n)) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(h->level_rows, rows.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
@@ -339,7 +372,7 @@ static int sweep(its_handle *h, double *x, const double *rhs)
     const CsrDev &L = h->mat[ITS_MAT_L];
     for (int l = 0; l < h->n_levels; ++l) {
         const int cnt = h->level_ptr[l + 1] - h->level_ptr[l];
-        launch_sweep_level(L, h->level_rows + h->level_ptr[l], cnt, x, rhs, h->D, h->stream);
+        launch_sweep_level(L, h->level_rows + h->level_ptr[l], cnt, h->level_nshort[l], x, rhs, h->D, h->stream);
     }
     HIPCHK(h, hipGetLastError());
     return ITS_OK;

@@ -58,6 +58,7 @@ struct its_handle {
     double last_residual = 0.0;
     // triangular sweep schedule (levels of L; colours when the matrix was colour-permuted)
     std::vector<int> level_ptr;           // host offsets into level_rows
+    std::vector<int> level_nshort;            // rows of each level with <= SWEEP_SHORT entries in L (listed first)
     int *level_rows = nullptr;            // device
     int n_levels = 0;
     // multicolour permutation (gs_order == ITS_GS_MULTICOLOR): new index -> old index

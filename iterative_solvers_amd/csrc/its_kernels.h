@@ -42,6 +42,7 @@ struct CsrDev {
     int sell_chunks = 0, sell_sigma = 0;
     int64_t sell_elems = 0;
     int *sell_chunk_ptr = nullptr, *sell_chunk_len = nullptr, *sell_col = nullptr, *sell_perm = nullptr;
+    int *sell_grp_start = nullptr;           // [ITS_NPART + 1] chunk-group range of every workgroup slot (work-balanced)
     double *sell_val = nullptr;
 };
 
@@ -115,7 +116,9 @@ void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t
 // Gauss-Seidel / triangular sweeps (kernels.hpp:451-473) by dependency level or colour.
 // rows[] lists the rows of one level; x[i] = (rhs[i] - sum_j L_ij x_j) / D[i], in-order fma.
 // ---------------------------------------------------------------------------------------
-void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, double *x,
+constexpr int SWEEP_SHORT = 16;            // rows of L up to this length take one lane, longer ones one wave
+// rows[0, n_short) must be the short rows of the level, rows[n_short, n_level_rows) the long ones
+void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int n_short, double *x,
                         const double *rhs, const double *D, hipStream_t s);
 
 }  // namespace its

@@ -620,11 +620,27 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_irr_kernel(
             *reinterpret_cast<double2 *>(&s_xg[oB_ + 2]) = make_double2(gB2, gB3);        \
         }                                                                                 \
     } while (0)
+    // the chain: LDS reads of 8 entries go out together, then the 8 multiply-adds run in CRS order
 #define IRR_CHAIN(jb, je)                                                                 \
-    for (int j = (jb); j < (je); ++j) {                                                   \
-        const double vv = s_val[j];                                                       \
-        if (EPI == EPI_JACOBI_REF && s_col[j] == row) diag = vv;                          \
-        else acc = fma(vv, s_xg[j], acc);                                                 \
+    {                                                                                     \
+        int j = (jb);                                                                     \
+        const int je_ = (je);                                                             \
+        for (; j + 8 <= je_; j += 8) {                                                    \
+            double vv[8], xx[8]; int cc[8];                                               \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                               \
+                vv[u] = s_val[j + u]; xx[u] = s_xg[j + u];                                \
+                if (EPI == EPI_JACOBI_REF) cc[u] = s_col[j + u];                          \
+            }                                                                             \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                               \
+                if (EPI == EPI_JACOBI_REF && cc[u] == row) diag = vv[u];                  \
+                else acc = fma(vv[u], xx[u], acc);                                        \
+            }                                                                             \
+        }                                                                                 \
+        for (; j < je_; ++j) {                                                            \
+            const double vv = s_val[j];                                                   \
+            if (EPI == EPI_JACOBI_REF && s_col[j] == row) diag = vv;                      \
+            else acc = fma(vv, s_xg[j], acc);                                             \
+        }                                                                                 \
     }
 
     for (int rb = rb0; rb < rb1; rb += rstep) {
@@ -884,43 +900,81 @@ void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t
 // chunk (values[chunk_ptr + j*64 + lane], CUDA_tests/helpers/utilities.cpp:321-337), so every
 // load is one fully coalesced 512-byte / 256-byte wave access.  perm[] maps chunk row -> row.
 // ======================================================================================
+constexpr int SELL_COOP = 512;   // chunks wider than this are shared by the four waves of the workgroup
+
 template <int EPI, bool DOT>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_sell_kernel(
     int n_rows, int n_chunks, const int *__restrict__ chunk_ptr, const int *__restrict__ chunk_len,
     const int *__restrict__ scol, const double *__restrict__ sval, const int *__restrict__ perm,
-    SpmvArgs a)
+    const int *__restrict__ grp_start, SpmvArgs a)
 {
     __shared__ double s_red[4];
+    __shared__ double s_part[4][ITS_WAVE];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int G = gridDim.x;
-    const int slot = xcd_slot(blockIdx.x, G);
-    const int64_t n_grp = ((int64_t)n_chunks + 3) / 4;      // 4 chunks (waves) per workgroup step
-    const int64_t g0 = (slot * n_grp) / G, g1 = ((slot + 1) * n_grp) / G;
+    const int slot = xcd_slot(blockIdx.x, gridDim.x);
+    const int g0 = grp_start[slot], g1 = grp_start[slot + 1];
     double lane_sum = 0.0, lane_max = 0.0;
-    for (int64_t grp = g0; grp < g1; ++grp) {
-        const int ch = (int)(grp * 4) + w;
-        if (ch < n_chunks) {
-            const int64_t cs = chunk_ptr[ch];
+    // columns [ja, jb) of one chunk: loads of 8 columns go out together, multiply-adds in column order
+#define SELL_RUN(cs, ja, jb, acc)                                                         \
+    {                                                                                     \
+        int j = (ja);                                                                     \
+        for (; j + 8 <= (jb); j += 8) {                                                   \
+            int c[8]; double v[8], xv[8];                                                 \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                               \
+                const int64_t idx = (cs) + (int64_t)(j + u) * 64 + lane;                  \
+                c[u] = scol[idx]; v[u] = sval[idx];                                       \
+            }                                                                             \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];              \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) acc = fma(v[u], xv[u], acc);    \
+        }                                                                                 \
+        for (; j < (jb); ++j) {                                                           \
+            const int64_t idx = (cs) + (int64_t)j * 64 + lane;                            \
+            acc = fma(sval[idx], a.x[scol[idx]], acc);                                    \
+        }                                                                                 \
+    }
+#define SELL_EPILOGUE(ch, acc)                                                            \
+    {                                                                                     \
+        const int row = perm[(ch) * 64 + lane];                                           \
+        if (row >= 0 && row < n_rows) {                                                   \
+            if (EPI == EPI_STORE) {                                                       \
+                a.y[row] = acc;                                                           \
+                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);                      \
+            } else if (EPI == EPI_RESIDUAL) {                                             \
+                const double r = a.b[row] - acc;                                          \
+                a.y[row] = r;                                                             \
+                lane_sum = fma(r, r, lane_sum);                                           \
+                lane_max = fmax(lane_max, fabs(r));                                       \
+            }                                                                             \
+        }                                                                                 \
+    }
+    for (int grp = g0; grp < g1; ++grp) {
+        for (int cc = 0; cc < 4; ++cc) {
+            const int ch = grp * 4 + cc;
+            if (ch >= n_chunks) break;
             const int len = chunk_len[ch];
-            double acc = 0.0;
-            for (int j = 0; j < len; ++j) {
-                const int64_t idx = cs + (int64_t)j * 64 + lane;
-                acc = fma(sval[idx], a.x[scol[idx]], acc);
-            }
-            const int row = perm[ch * 64 + lane];
-            if (row >= 0 && row < n_rows) {
-                if (EPI == EPI_STORE) {
-                    a.y[row] = acc;
-                    if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
-                } else if (EPI == EPI_RESIDUAL) {
-                    const double r = a.b[row] - acc;
-                    a.y[row] = r;
-                    lane_sum = fma(r, r, lane_sum);
-                    lane_max = fmax(lane_max, fabs(r));
+            const int64_t cs = chunk_ptr[ch];
+            if (len > SELL_COOP) {
+                // wide chunk: wave w takes a quarter of the columns, partial sums combined in wave order
+                const int q = (len + 3) >> 2;
+                const int ja = min(len, w * q), jb = min(len, ja + q);
+                double acc = 0.0;
+                SELL_RUN(cs, ja, jb, acc)
+                s_part[w][lane] = acc;
+                __syncthreads();
+                if (w == 0) {
+                    acc = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
+                    SELL_EPILOGUE(ch, acc)
                 }
+                __syncthreads();
+            } else if (cc == w) {
+                double acc = 0.0;
+                SELL_RUN(cs, 0, len, acc)
+                SELL_EPILOGUE(ch, acc)
             }
         }
     }
+#undef SELL_RUN
+#undef SELL_EPILOGUE
     if (DOT || EPI == EPI_RESIDUAL) {
         const double bs = block_sum(lane_sum, s_red);
         if (t == 0 && a.part_sum) a.part_sum[blockIdx.x] = bs;
@@ -936,7 +990,7 @@ void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s
     dim3 g(ITS_NPART), b(ITS_BLOCK);
 #define ITS_LAUNCH(E, D) \
     hipLaunchKernelGGL((spmv_sell_kernel<E, D>), g, b, 0, s, A.n_rows, A.sell_chunks, A.sell_chunk_ptr, \
-                       A.sell_chunk_len, A.sell_col, A.sell_val, A.sell_perm, a)
+                       A.sell_chunk_len, A.sell_col, A.sell_val, A.sell_perm, A.sell_grp_start, a)
     if (epi == EPI_RESIDUAL) ITS_LAUNCH(EPI_RESIDUAL, false);
     else if (a.dotv) ITS_LAUNCH(EPI_STORE, true);
     else ITS_LAUNCH(EPI_STORE, false);
@@ -1195,29 +1249,92 @@ void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t
 // x_i = (rhs_i - sum_j L_ij x_j) / D_i with the reference's in-order fused chain
 // (kernels.hpp:460-472).  Rows of one level never read each other.
 // ======================================================================================
+// Short rows (<= SWEEP_SHORT entries, listed first) take one lane each, gathers eight at a time, in the
+// first `short_blocks` workgroups.  Every longer row gets a whole wave of the remaining workgroups:
+// SWEEP_CHUNK entries of col/val are loaded coalesced, x gathered in parallel, (val, x) parked in a
+// wave-private LDS strip, and the chain runs over the strip in CRS order — the same operations in the same
+// order as the reference, whatever the row length; the level's long rows run side by side.
+constexpr int SWEEP_CHUNK = 4 * ITS_WAVE;   // entries of a long row staged per trip (4 per lane)
+
 __global__ __launch_bounds__(ITS_BLOCK) void sweep_level_kernel(
     const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
-    const int *__restrict__ rows, int n_level_rows, double *x, const double *__restrict__ rhs,
-    const double *__restrict__ D)
+    const int *__restrict__ rows, int n_level_rows, int n_short, int short_blocks, double *x,
+    const double *__restrict__ rhs, const double *__restrict__ D)
 {
-    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
-    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
-    for (int64_t k = tid; k < n_level_rows; k += nth) {
+    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][SWEEP_CHUNK];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if ((int)blockIdx.x < short_blocks) {
+        const int64_t nth = (int64_t)short_blocks * ITS_BLOCK;
+        for (int64_t k = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x; k < n_short; k += nth) {
+            const int row = rows ? rows[k] : (int)k;
+            const int j0 = rp[row], j1 = rp[row + 1];
+            double s = 0.0;
+            for (int j = j0; j < j1; j += 8) {
+                int c[8]; double v[8], xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = j + u < j1;
+                    const int jj = ok ? j + u : j;
+                    c[u] = col[jj]; v[u] = val[jj];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (j + u < j1) s = fma(v[u], xv[u], s);
+            }
+            x[row] = (rhs[row] - s) / D[row];
+        }
+        return;
+    }
+    const int64_t wstride = (int64_t)(gridDim.x - short_blocks) * (ITS_BLOCK / ITS_WAVE);
+    for (int64_t k = n_short + (int64_t)(blockIdx.x - short_blocks) * (ITS_BLOCK / ITS_WAVE) + w; k < n_level_rows; k += wstride) {
         const int row = rows ? rows[k] : (int)k;
-        double s = 0.0;
-        for (int j = rp[row]; j < rp[row + 1]; ++j) s = fma(val[j], x[col[j]], s);
-        x[row] = (rhs[row] - s) / D[row];
+        const int rj0 = rp[row], rj1 = rp[row + 1];
+        double acc = 0.0;
+        // chunk in flight: (val, x[col]) of entries c0 + l + 64 u, u = 0..3
+        double vv[4], xg[4];
+#define SWEEP_LOAD(c0v)                                                                   \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                   \
+            const int e_ = (c0v) + l + ITS_WAVE * u;                                      \
+            const int cc_ = e_ < rj1 ? col[e_] : 0;                                       \
+            vv[u] = e_ < rj1 ? val[e_] : 0.0;                                             \
+            xg[u] = x[cc_];                                                               \
+        }
+        SWEEP_LOAD(rj0)
+        for (int c0 = rj0; c0 < rj1; c0 += SWEEP_CHUNK) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s_vx[w][l + ITS_WAVE * u] = make_double2(vv[u], xg[u]);
+            SWEEP_LOAD(c0 + SWEEP_CHUNK)                  // next chunk goes out before the chain runs
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int ne = min(SWEEP_CHUNK, rj1 - c0);
+            int q = 0;
+            for (; q + 8 <= ne; q += 8) {
+                double2 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = s_vx[w][q + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fma(p[u].x, p[u].y, acc);
+            }
+            for (; q < ne; ++q) { const double2 p1 = s_vx[w][q]; acc = fma(p1.x, p1.y, acc); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+#undef SWEEP_LOAD
+        if (l == 0) x[row] = (rhs[row] - acc) / D[row];
     }
 }
 
-void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, double *x,
+void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int n_short, double *x,
                         const double *rhs, const double *D, hipStream_t s)
 {
-    int g = (n_level_rows + ITS_BLOCK - 1) / ITS_BLOCK;
-    if (g > ITS_NPART) g = ITS_NPART;
-    if (g < 1) g = 1;
-    hipLaunchKernelGGL(sweep_level_kernel, dim3(g), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val,
-                       rows, n_level_rows, x, rhs, D);
+    if (n_level_rows <= 0) return;
+    if (!rows) n_short = n_level_rows;                       // identity order has no long-row list
+    int gs = (n_short + ITS_BLOCK - 1) / ITS_BLOCK;
+    if (gs > 4 * ITS_NPART) gs = 4 * ITS_NPART;
+    const int n_long = n_level_rows - n_short;
+    int gl = (n_long + 3) / 4;
+    if (gl > 4 * ITS_NPART) gl = 4 * ITS_NPART;
+    hipLaunchKernelGGL(sweep_level_kernel, dim3(gs + gl), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val,
+                       rows, n_level_rows, n_short, gs, x, rhs, D);
 }
 
 }  // namespace its
