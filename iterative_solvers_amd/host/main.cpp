@@ -16,12 +16,14 @@ void preprocessing(argType *args, Solver<VT> *solver)
     std::cout << "Allocating space for general CPU structs" << std::endl;
     args->normed_residuals.assign(args->loop_params.max_iters / args->loop_params.residual_check_len + 1, 0.0);
     convert_to_crs(args->coo_mat, args->crs_mat);                                // main.cpp:221-229
+    solver->reorder_multicolor(args);          // GS_ORDER = multicolor only: A <- P A P^T, rows colour by colour
     solver->allocate_cpu_solver_structs(args);                                   // main.cpp:206-218
     extract_diag(args->coo_mat, solver->D);                                      // main.cpp:268
     generate_vector(solver->b, args->vec_size, args->loop_params.init_b);        // main.cpp:271-276
     scale_vector(solver->b, scaling_row_elems);
     generate_vector(solver->x_old, args->vec_size, args->loop_params.init_x);
     scale_vector(solver->x_old, scaling_row_elems);
+    solver->permute_vector(solver->b); solver->permute_vector(solver->x_old);   // no-op unless reordered
     solver->upload_vectors();
     double r0_inf = 0, r0_two = 0;
     solver->init_residual(&r0_inf, &r0_two);                                     // main.cpp:307
@@ -42,6 +44,7 @@ void run_solver(int argc, char *argv[])
     if (const char *e = getenv("ITS_TOL")) args->loop_params.tol = atof(e);
     if (const char *e = getenv("ITS_GMRES_RESTART_LEN")) args->loop_params.gmres_restart_len = atoi(e);
     Solver<VT> *solver = new Solver<VT>(args->solver_type, args->preconditioner_type);
+    if (const char *e = getenv("ITS_GS_ORDER")) solver->gs_order = std::string(e) == "multicolor" ? ITS_GS_MULTICOLOR : ITS_GS_LEVEL;
     std::cout << "Reading Matrix" << std::endl;
     read_mtx(args->matrix_file_name, &args->coo_mat);
     preprocessing<VT>(args, solver);

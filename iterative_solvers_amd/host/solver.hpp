@@ -28,6 +28,8 @@ class Solver {
 public:
     std::vector<VT> x_star, D, b, x_old;
     int gmres_restart_length = GMRES_RESTART_LEN;
+    int gs_order = GS_ORDER;                   // config.mk GS_ORDER (run-time override: ITS_GS_ORDER)
+    std::vector<int> perm;                     // multicolour order, new -> old (empty = natural order)
 
     Solver(std::string st, std::string pt) : solver_type(std::move(st)), preconditioner_type(std::move(pt))
     {
@@ -35,6 +37,33 @@ public:
         if (its_create(&h, DEVICE) != ITS_OK) { printf("ERROR: Solver: no HIP device / libits_hip failed to start.\n"); exit(1); }
     }
     ~Solver() { if (h) its_destroy(h); }
+
+    // GS_ORDER = multicolor: the reference's natural-order sweep (gauss_seidel.hpp:41-247) runs on P A P^T with
+    // rows ordered colour by colour (its_hip.h, "Gauss-Seidel ordering helpers"); b and x0 are permuted alike
+    // and x_star comes back in the original numbering.
+    void reorder_multicolor(argType *args)
+    {
+        if (solver_type != "gauss-seidel" || gs_order != ITS_GS_MULTICOLOR) return;
+        CRSMtxData &A = args->crs_mat;
+        int n_colors = 0;
+        perm.assign(A.n_rows, 0);
+        check(its_multicolor_order(A.n_rows, A.row_ptr.data(), A.col.data(), perm.data(), &n_colors), "its_multicolor_order");
+        CRSMtxData B = A;
+        check(its_permute_crs(A.n_rows, A.row_ptr.data(), A.col.data(), A.val.data(), perm.data(),
+                              B.row_ptr.data(), B.col.data(), B.val.data()), "its_permute_crs");
+        A = B;
+        COOMtxData &C = args->coo_mat;          // keep the COO image (split_L_U, extract_diag) in step
+        for (int i = 0; i < A.n_rows; ++i)
+            for (int j = A.row_ptr[i]; j < A.row_ptr[i + 1]; ++j) { C.I[j] = i; C.J[j] = A.col[j]; C.values[j] = A.val[j]; }
+        std::cout << "Multicolour Gauss-Seidel ordering: " << n_colors << " colours" << std::endl;
+    }
+    void permute_vector(std::vector<VT> &v) const
+    {
+        if (perm.empty()) return;
+        std::vector<VT> o(v.size());
+        for (size_t i = 0; i < v.size(); ++i) o[i] = v[perm[i]];
+        v.swap(o);
+    }
 
     // allocate_cpu_solver_structs + the CRS hand-over (reference main.cpp:206-229; GS: gauss_seidel.hpp:249-630)
     void allocate_cpu_solver_structs(argType *args)
@@ -58,12 +87,20 @@ public:
     {
         const int pre = preconditioner_type == "gauss-seidel" ? ITS_PRECOND_GS : preconditioner_type == "jacobi" ? ITS_PRECOND_JACOBI : ITS_PRECOND_NONE;
         check(its_set_option(h, "gmres_givens", GMRES_GIVENS), "its_set_option");
-        check(its_solver_setup(h, kind(), gmres_restart_length, pre, JACOBI_MODE, GS_ORDER), "init_structs");
+        check(its_solver_setup(h, kind(), gmres_restart_length, pre, JACOBI_MODE, gs_order), "init_structs");
     }
     // iterate + the value record_residual_norm computes + exchange_arrays (solver_harness.hpp:43-90)
     void iterate(int iter_count, VT *residual_norm) { check(its_iterate(h, iter_count, residual_norm), "iterate"); }
     void exchange_arrays(int) {}                        // pointer swaps happen on the device inside iterate
     void restart_gmres(int iter_count) { check(its_gmres_restart(h, iter_count), "restart_gmres"); }
-    void save_x_star(int iter_count) { check(its_download_x(h, x_star.data(), (int)x_star.size(), iter_count), "save_x_star"); }
+    void save_x_star(int iter_count)
+    {
+        check(its_download_x(h, x_star.data(), (int)x_star.size(), iter_count), "save_x_star");
+        if (!perm.empty()) {
+            std::vector<VT> o(x_star.size());
+            for (size_t i = 0; i < x_star.size(); ++i) o[perm[i]] = x_star[i];
+            x_star.swap(o);
+        }
+    }
     void final_residual(VT *r) { check(its_final_residual(h, r), "record_residual_norm"); }
 };

@@ -62,3 +62,30 @@ def test_cli_matches_reference_output(key):
             bound = np.maximum(bound, 5e-2 * w[ok])
         bad = np.nonzero(np.abs(g[ok] - w[ok]) > bound)[0]
         assert bad.size == 0, (key, int(bad[0]), float(g[ok][bad[0]]), float(w[ok][bad[0]]))
+
+
+@pytest.mark.parametrize("m", ["lap2d_16", "cd27_6", "pl_200"])
+def test_cli_multicolor_gauss_seidel(m):
+    """GS_ORDER = multicolor in the C++ host (run-time switch ITS_GS_ORDER): printed history equals the
+    oracle's natural-order sweep on the SAME permuted system P A P^T (identical arithmetic)."""
+    import sys
+    sys.path.insert(0, HERE)
+    import oracle_py as orc
+    from iterative_solvers_amd import capi, solver as S
+    n, I, J, V = S.read_mtx(os.path.join(G, m + ".mtx"))
+    rp, col, val = S.coo_to_crs(n, I, J, V)
+    perm, nc = capi.multicolor_order(rp, col)
+    rpp, cp, vp = capi.permute_crs(rp, col, val, perm)
+    b = np.ones(n)
+    orc.set_threads(1)
+    ref = orc.solve(rpp, cp, vp, b, b.copy(), orc.GAUSS_SEIDEL, max_iters=200, tol=1e-10)
+    env = dict(os.environ, ITS_GS_ORDER="multicolor", ITS_TOL="1e-10", ITS_MAX_ITERS="200")
+    out = subprocess.run([EXE, os.path.join(G, m + ".mtx"), "-gs", "-scale", "none"], env=env,
+                         capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Multicolour Gauss-Seidel ordering: %d colours" % nc in out.stdout
+    hist = np.array([float(v) for _, v in LINE.findall(out.stdout)])
+    want = ref["history"]
+    k = min(len(hist), len(want))
+    assert k > 0 and abs(len(hist) - len(want)) <= 1
+    assert np.all(np.abs(hist[:k] - want[:k]) <= 1e-10 * np.maximum(want[:k], 1e-2 * want[0]))
