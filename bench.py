@@ -109,7 +109,10 @@ def main():
     N = a.grid
 
     t_gen = time.time()
-    sol = S.Solver("conjugate-gradient", device=local_rank, spmv_format=fmt)
+    # rehearsal of the N > 1 path on a one-GPU box: ITS_BENCH_TRANSPORT=host puts every rank on GPU 0 and
+    # moves halo entries / scalars through the TCP rendezvous instead of RCCL (never a reported number)
+    host_transport = os.environ.get("ITS_BENCH_TRANSPORT", "rccl") == "host"
+    sol = S.Solver("conjugate-gradient", device=0 if host_transport else local_rank, spmv_format=fmt)
     h = sol.handle
     if world == 1:
         rp, col, val = matgen.laplace3d_7pt(N)
@@ -122,7 +125,10 @@ def main():
         rp, colg, val = matgen.laplace3d_7pt_slab(N, rank * N, (rank + 1) * N, world * N)
         n = len(rp) - 1
         nnz = len(colg)
-        D.init_comm(h, rank, world, rdzv)
+        if host_transport:
+            D.init_comm_host(h, rank, world, rdzv)
+        else:
+            D.init_comm(h, rank, world, rdzv)
         D.upload_slab(h, rdzv, world * n, rank * n, rp, colg, val, fmt)
         diag = np.full(n, 6.0)
         h.upload_vectors(diag, np.ones(n), np.ones(n))
@@ -163,16 +169,16 @@ def main():
         xd = h.to_dev(np.ones(n + 2 * N * N)); yd = h.dev_alloc(8 * n)
         roof = None
         spmv_all = {}
-        if world == 1:
+        if inloop_spmv_ms > 0:
             # the kernel as it runs INSIDE the CG loop (caches in the loop's state): its average
             # launch duration is what rocprofv3 --stats reports for the same command
             k_ms = inloop_spmv_ms
             ach = spmv_bytes(n, nnz) / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic("spmv_stream4_kernel<0, true>") if fmt == capi.FMT_CSR_EXACT else None,
+                    "traffic": pmc_traffic("spmv_stream4_kernel<0, true>") if (fmt == capi.FMT_CSR_EXACT and world == 1 and N == 256) else None,
                     "kernel": "its::spmv_stream4_kernel<0, true> (CSR SpMV + fused p.Ap partials)" if fmt == capi.FMT_CSR_EXACT else a.format,
                     "kernel_ms": k_ms, "algorithmic_bytes": spmv_bytes(n, nnz)}
-            for nm, f in (("exact", capi.FMT_CSR_EXACT), ("vector", capi.FMT_CSR_VECTOR)):
+            for nm, f in ((("exact", capi.FMT_CSR_EXACT), ("vector", capi.FMT_CSR_VECTOR)) if world == 1 else ()):
                 h.spmv_timed(xd, yd, f, reps=3)
                 ms = h.spmv_timed(xd, yd, f, reps=a.spmv_reps)
                 spmv_all[nm] = {"ms": ms, "GB/s": spmv_bytes(n, nnz) / (ms * 1e-3) / 1e9}
@@ -180,12 +186,12 @@ def main():
         if not a.no_cpu and world == 1:
             cpu = cpu_baseline(rp, col, val, n)
         out = {
-            "metric": "cg_iters_per_sec", "value": its_per_s * world, "unit": "it/s (256^3-slab iterations)",
+            "metric": "cg_iters_per_sec", "value": its_per_s * world, "unit": f"it/s ({N}^3-slab iterations)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"CG fp64, 3-D 7-pt Laplacian, {N}^3 rows per GPU (grid {N}x{N}x{N * world}), b=1, x0=1, -scale none",
                        "rows_per_gpu": n, "nnz_per_gpu": nnz, "spmv_format": a.format,
-                       "parallelism": f"row-block z-slabs x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"row-block z-slabs x{world}" + (" (HOST rehearsal transport, one GPU)" if host_transport else " over RCCL")) if world > 1 else "single GPU"},
             "cg_GBps_algorithmic": cg_iter_bytes(n, nnz) * its_per_s / 1e9,
             "cg_frac_of_hbm_peak": cg_iter_bytes(n, nnz) * its_per_s / 1e9 / HBM_PEAK_GBS,
             "async_loop_ms_per_step": async_ms,

@@ -123,6 +123,59 @@ def init_comm(handle: capi.Handle, rank: int, world: int, rdzv) -> None:
     handle.check(L.its_comm_init(handle.h, rank, world, buf), "its_comm_init")
 
 
+_XCB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
+_RCB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+
+def init_comm_host(handle: capi.Handle, rank: int, world: int, rdzv) -> None:
+    """HOST test transport (its_comm_init_host): halo entries and scalars cross ranks through the TCP
+    rendezvous, so several ranks can share one GPU.  Everything else (pack kernel, interior/boundary
+    SpMV, fused updates) runs exactly as with RCCL.  Used by tests and by `bench.py` rehearsals
+    (ITS_BENCH_TRANSPORT=host); never the production data path."""
+
+    def exchange(user, send, send_off, recv, recv_off, nbr, n_nbr):
+        try:
+            nb = [nbr[k] for k in range(n_nbr)]
+            so = [send_off[k] for k in range(n_nbr + 1)]
+            data = np.ctypeslib.as_array(send, (max(so[-1], 1),))[:so[-1]] if n_nbr else np.zeros(0)
+            meta = np.array([n_nbr] + nb + so, dtype=np.int64)
+            blobs = rdzv.allgather_bytes(meta.tobytes() + np.ascontiguousarray(data).tobytes())
+            n_recv = recv_off[n_nbr] if n_nbr else 0
+            out = np.ctypeslib.as_array(recv, (max(n_recv, 1),))
+            for k in range(n_nbr):
+                b = blobs[nb[k]]
+                nn = int(np.frombuffer(b[:8], dtype=np.int64)[0])
+                hdr = np.frombuffer(b[8:8 * (2 + 2 * nn)], dtype=np.int64)
+                their_nbr, their_off = hdr[:nn], hdr[nn:]
+                payload = np.frombuffer(b[8 * (2 + 2 * nn):], dtype=np.float64)
+                j = int(np.nonzero(their_nbr == rank)[0][0])
+                seg = payload[their_off[j]:their_off[j + 1]]
+                assert len(seg) == recv_off[k + 1] - recv_off[k]
+                out[recv_off[k]:recv_off[k + 1]] = seg
+            return 0
+        except Exception:  # noqa: BLE001
+            import traceback; traceback.print_exc()
+            return 1
+
+    def allreduce(user, vals, count, op):
+        try:
+            mine = np.array([vals[i] for i in range(count)])
+            parts = [np.frombuffer(b, dtype=np.float64) for b in rdzv.allgather_bytes(mine.tobytes())]
+            res = np.max(parts, axis=0) if op == 1 else np.sum(parts, axis=0)   # rank order: deterministic
+            for i in range(count):
+                vals[i] = res[i]
+            return 0
+        except Exception:  # noqa: BLE001
+            import traceback; traceback.print_exc()
+            return 1
+
+    xcb, rcb = _XCB(exchange), _RCB(allreduce)
+    handle._host_cbs = (xcb, rcb)             # keep the trampolines alive as long as the handle
+    handle.check(handle.L.its_comm_init_host(handle.h, rank, world, C.cast(xcb, C.c_void_p), C.cast(rcb, C.c_void_p), None),
+                 "its_comm_init_host")
+
+
 def upload_slab(handle: capi.Handle, comm, n_global: int, row_begin: int, row_ptr, col_global, val,
                 fmt=capi.FMT_CSR_EXACT) -> PartitionPlan:
     """Plan the partition (collective) and give the local matrix + exchange plan to the library."""

@@ -14,52 +14,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from iterative_solvers_amd import capi, distributed as D, matgen  # noqa: E402
 from iterative_solvers_amd.rendezvous import Rendezvous  # noqa: E402
 
-XCB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
-                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
-RCB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
-
-
 def main():
     kind, solver, out = sys.argv[1], sys.argv[2], sys.argv[3]
     rdzv = Rendezvous()
     rank, world = rdzv.rank, rdzv.world
 
-    def exchange(user, send, send_off, recv, recv_off, nbr, n_nbr):
-        try:
-            nb = [nbr[k] for k in range(n_nbr)]
-            so = [send_off[k] for k in range(n_nbr + 1)]
-            data = np.ctypeslib.as_array(send, (max(so[-1], 1),))[:so[-1]] if n_nbr else np.zeros(0)
-            meta = np.array([n_nbr] + nb + so, dtype=np.int64)
-            blobs = rdzv.allgather_bytes(meta.tobytes() + np.ascontiguousarray(data).tobytes())
-            for k in range(n_nbr):
-                b = blobs[nb[k]]
-                nn = int(np.frombuffer(b[:8], dtype=np.int64)[0])
-                hdr = np.frombuffer(b[8:8 * (2 + 2 * nn)], dtype=np.int64)
-                their_nbr, their_off = hdr[:nn], hdr[nn:]
-                payload = np.frombuffer(b[8 * (2 + 2 * nn):], dtype=np.float64)
-                j = int(np.nonzero(their_nbr == rank)[0][0])
-                seg = payload[their_off[j]:their_off[j + 1]]
-                assert len(seg) == recv_off[k + 1] - recv_off[k]
-                for i, v in enumerate(seg):
-                    recv[recv_off[k] + i] = v
-            return 0
-        except Exception:  # noqa: BLE001
-            import traceback; traceback.print_exc()
-            return 1
-
-    def allreduce(user, vals, count, op):
-        try:
-            mine = np.array([vals[i] for i in range(count)])
-            parts = [np.frombuffer(b, dtype=np.float64) for b in rdzv.allgather_bytes(mine.tobytes())]
-            res = np.max(parts, axis=0) if op == 1 else np.sum(parts, axis=0)   # rank order: deterministic
-            for i in range(count):
-                vals[i] = res[i]
-            return 0
-        except Exception:  # noqa: BLE001
-            import traceback; traceback.print_exc()
-            return 1
-
-    xcb, rcb = XCB(exchange), RCB(allreduce)
     if kind == "lap":
         N, NZ = 12, 24
         cuts = np.linspace(0, NZ, world + 1).astype(int)
@@ -80,7 +39,7 @@ def main():
         diag = np.zeros(r1 - r0); m = rows == colg; diag[rows[m] - r0] = val[m]
     n_loc = len(rp) - 1
     h = capi.Handle(0)
-    h.check(h.L.its_comm_init_host(h.h, rank, world, C.cast(xcb, C.c_void_p), C.cast(rcb, C.c_void_p), None), "its_comm_init_host")
+    D.init_comm_host(h, rank, world, rdzv)
     plan = D.upload_slab(h, rdzv, n_global, row_begin, rp, colg, val, capi.FMT_CSR_EXACT)
     h.upload_vectors(diag, np.ones(n_loc), np.ones(n_loc))
     r0_inf, r0_two = h.init_residual()
