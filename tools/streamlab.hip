@@ -161,6 +161,63 @@ __global__ __launch_bounds__(BLK) void k_stream(int nb, const int4 *__restrict__
     if (sink == 1.2345e-300 || isink == 0x7fffffff) out[t] = sink;
 }
 
+// burst-store variant: each workgroup takes KB consecutive row blocks per turn, parks the results in LDS
+// and writes them as one contiguous burst (KB * ~1.75 KB) every KB trips
+template <int KB>
+__global__ __launch_bounds__(BLK) void k_stream_burst(int nb, const int4 *__restrict__ desc, const int *__restrict__ rp,
+                                                      const int *__restrict__ col, const double *__restrict__ val,
+                                                      const double *x, double *__restrict__ y, double *out)
+{
+    __shared__ __attribute__((aligned(16))) double s_val[2][CAP + 8];
+    __shared__ __attribute__((aligned(16))) int s_col[2][CAP + 8];
+    __shared__ int s_rp[2][BLK + 4];
+    __shared__ double s_y[KB * BLK];
+    const int t = threadIdx.x, G = gridDim.x;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int X0 = (int)(((int64_t)xcd * nb) / 8), X1 = (int)(((int64_t)(xcd + 1) * nb) / 8);
+    const int rstep = G >> 3;
+#define RBX(i) (X0 + ((i) / KB) * (rstep * KB) + jx * KB + ((i) % KB))
+    int niter = 0;
+    while (RBX(niter) < X1) ++niter;
+    int4 rcA, rcB; double2 rvA0, rvA1, rvB0, rvB1; int rrp = 0;
+    rcA = rcB = make_int4(0, 0, 0, 0); rvA0 = rvA1 = rvB0 = rvB1 = make_double2(0, 0);
+    int cur = 0; bool have = false;
+    int gstart = 0;
+    int4 d = make_int4(0, 0, 0, 0), dn = d;
+    if (niter > 0) { d = desc[RBX(0)]; dn = desc[RBX(niter > 1 ? 1 : 0)]; }
+    for (int it = 0; it < niter; ++it) {
+        const int4 dnn = desc[RBX(min(it + 2, niter - 1))];
+        const int nr = d.y, row = d.x + t;
+        if (it % KB == 0) gstart = d.x;
+        if (!have) ISSUE(d);
+        COMMIT(d, cur); __syncthreads();
+        have = false;
+        if (it + 1 < niter) { ISSUE(dn); have = true; }
+        if (t < nr) {
+            const int base = d.z & ~3;
+            const int j0 = s_rp[cur][t] - base, j1 = s_rp[cur][t + 1] - base;
+            double acc = 0.0;
+            for (int j = j0; j < j1; j += 8) {
+                int c[8]; double v[8], xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int jj = (j + u < j1) ? j + u : j; c[u] = s_col[cur][jj]; v[u] = s_val[cur][jj]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (j + u < j1) acc = fma(v[u], xv[u], acc);
+            }
+            s_y[row - gstart] = acc;
+        }
+        if (it % KB == KB - 1 || it == niter - 1) {
+            const int gcount = d.x + nr - gstart;
+            __syncthreads();
+            for (int i = t; i < gcount; i += BLK) y[gstart + i] = s_y[i];
+        }
+        cur ^= 1; d = dn; dn = dnn;
+    }
+#undef RBX
+}
+
 // ---------------------------------------------------------------- wave-specialised: a fifth wave does the y stores
 // (stores and loads share the in-order vmcnt queue on gfx9: a walker wave that also stores must
 // wait for the store's acknowledge before it sees its next prefetch)
@@ -295,7 +352,10 @@ int main(int argc, char **argv)
     { float ms = time_ms(s, reps, [&] { CK(hipMemsetAsync(d_y, 0, n * 8, s)); }); printf("memset %lld MB: %.4f ms (%.0f GB/s)\n", (long long)(n * 8 >> 20), ms, n * 8.0 / ms / 1e6); }
 #define RUN(ST) do { float ms = time_ms(s, reps, [&] { hipLaunchKernelGGL((k_stream<ST, CAP>), dim3(1024), dim3(BLK), 0, s, nb, d_desc, d_rp, d_col, d_val, d_x, d_y, d_out); }); \
         printf("k_stream stage %d: %.4f ms (stream %.0f GB/s, full %.0f GB/s)\n", ST, ms, stream_bytes / ms / 1e6, full_bytes / ms / 1e6); } while (0)
-    RUN(0); RUN(1); RUN(2); RUN(6); RUN(3); RUN(4); RUN(5); RUN(9); RUN(8); RUN(4);
+    RUN(3); RUN(4);
+#define RUNB(K, GRID) do { float ms = time_ms(s, reps, [&] { hipLaunchKernelGGL((k_stream_burst<K>), dim3(GRID), dim3(BLK), 0, s, nb, d_desc, d_rp, d_col, d_val, d_x, d_y, d_out); }); \
+        printf("k_stream_burst K=%d grid %d: %.4f ms (full %.0f GB/s)\n", K, GRID, ms, full_bytes / ms / 1e6); } while (0)
+    RUNB(1, 1024); RUNB(2, 1024); RUNB(4, 768); RUNB(4, 1024); RUNB(8, 768); RUNB(16, 512); RUNB(8, 512);
     {
         constexpr int CAPW = 1280;
         std::vector<int4> dw;
