@@ -177,7 +177,10 @@ def main():
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": pmc_traffic("spmv_stream4_kernel<0, true>") if (fmt == capi.FMT_CSR_EXACT and world == 1 and N == 256) else None,
                     "kernel": "its::spmv_stream4_kernel<0, true> (CSR SpMV + fused p.Ap partials)" if fmt == capi.FMT_CSR_EXACT else a.format,
-                    "kernel_ms": k_ms, "algorithmic_bytes": spmv_bytes(n, nnz)}
+                    "kernel_ms": k_ms, "algorithmic_bytes": spmv_bytes(n, nnz),
+                    # what the kernel is asked to move: the 7-pt matrix has 7 distinct col-row offsets, so the
+                    # exact kernel streams a 1-byte offset index instead of the 4-byte column (lossless)
+                    "streamed_bytes": spmv_bytes(n, nnz) - (3 * nnz if (fmt == capi.FMT_CSR_EXACT and os.environ.get("ITS_SPMV_IDX", "1") != "0") else 0)}
             for nm, f in ((("exact", capi.FMT_CSR_EXACT), ("vector", capi.FMT_CSR_VECTOR)) if world == 1 else ()):
                 h.spmv_timed(xd, yd, f, reps=3)
                 ms = h.spmv_timed(xd, yd, f, reps=a.spmv_reps)

@@ -15,7 +15,7 @@
 static void free_csr(CsrDev &A)
 {
     dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_row); dfree(A.blk_desc);
-    dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start);
+    dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict);
     A = CsrDev();
 }
 
@@ -195,6 +195,31 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     if (nnz) {
         HIPCHK(h, hipMemcpy(A.col, col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(A.val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    {
+        // column-offset dictionary: at most 256 distinct (col - row) over the whole matrix
+        const int64_t span = (int64_t)n_rows + n_cols + 1;
+        std::vector<int16_t> slot((size_t)span, (int16_t)-1);
+        std::vector<int> dict;
+        std::vector<unsigned char> cidx((size_t)nnz + CSR_PAD, 0);
+        bool ok = nnz > 0 && getenv("ITS_NO_OFFSET_DICT") == nullptr;
+        for (int i = 0; i < n_rows && ok; ++i)
+            for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+                int16_t &sl = slot[(size_t)(col[k] - i + n_rows)];
+                if (sl < 0) {
+                    if (dict.size() == 256) { ok = false; break; }
+                    sl = (int16_t)dict.size();
+                    dict.push_back(col[k] - i);
+                }
+                cidx[k] = (unsigned char)sl;
+            }
+        if (ok) {
+            A.n_off = (int)dict.size();
+            dict.resize(256, 0);
+            if (dalloc(h, &A.cidx, cidx.size()) || dalloc(h, &A.off_dict, 256)) return ITS_EHIP;
+            HIPCHK(h, hipMemcpy(A.cidx, cidx.data(), cidx.size(), hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(A.off_dict, dict.data(), 256 * sizeof(int), hipMemcpyHostToDevice));
+        }
     }
     std::vector<int> blk;
     build_stream_plan(n_rows, row_ptr, blk);

@@ -31,6 +31,12 @@ struct CsrDev {
     int64_t nnz = 0;
     int *row_ptr = nullptr, *col = nullptr;   // col/val padded by CSR_PAD elements
     double *val = nullptr;
+    // column-offset dictionary (banded / stencil-class matrices): when the whole matrix has at most 256
+    // distinct values of col - row, cidx[k] is the 1-byte dictionary index of entry k (padded like col)
+    // and the exact SpMV streams it instead of the 4-byte column: 9 instead of 12 bytes per nonzero
+    unsigned char *cidx = nullptr;
+    int *off_dict = nullptr;                  // [256]
+    int n_off = 0;                            // 0 = not eligible
     // stream plan
     int n_blocks = 0;
     int *blk_row = nullptr;

@@ -345,18 +345,21 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
 // --------------------------------------------------------------------------------------
 struct StageRegs { int4 cA, cB; double2 vA0, vA1, vB0, vB1; int rp; };
 
-template <int EPI, bool DOT>
+template <int EPI, bool DOT, bool IDX>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
     int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
-    const int *__restrict__ col, const double *__restrict__ val, int n_rows, SpmvArgs a)
+    const int *__restrict__ col, const double *__restrict__ val, int n_rows,
+    const unsigned char *__restrict__ cidx, const int *__restrict__ off_dict, SpmvArgs a)
 {
     __shared__ __attribute__((aligned(16))) double s_val[2][S2_CAP];
-    __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];
+    __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];    // IDX: col - row, decoded at commit
     __shared__ int s_rp[2][ITS_BLOCK + 4];
+    __shared__ int s_dict[IDX ? 256 : 1];
     __shared__ double s_red[4];
 
     const int t = threadIdx.x;
     const int G = gridDim.x;
+    if (IDX) { s_dict[t] = off_dict[t]; __syncthreads(); }
     int rb0, rb1, rstep;
     if (a.map_mode == 0) {
         const int slot = xcd_slot(blockIdx.x, G);
@@ -382,26 +385,32 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         const int iA_ = base_ + 4 * t, iB_ = iA_ + 4 * ITS_BLOCK;                         \
         const int jA_ = iA_ < (d).w ? iA_ : 0, jB_ = iB_ < (d).w ? iB_ : 0;               \
         const int jr_ = t < ((d).y & 0xffff) ? (d).x + t : 0;                             \
-        R.cA = ld_i4<0>(col + jA_);                                                       \
+        if (IDX) R.cA.x = *reinterpret_cast<const int *>(cidx + jA_);                     \
+        else R.cA = ld_i4<0>(col + jA_);                                                  \
         R.vA0 = ld_d2<0>(val + jA_);                                                      \
         R.vA1 = ld_d2<0>(val + jA_ + 2);                                                  \
-        R.cB = ld_i4<0>(col + jB_);                                                       \
+        if (IDX) R.cB.x = *reinterpret_cast<const int *>(cidx + jB_);                     \
+        else R.cB = ld_i4<0>(col + jB_);                                                  \
         R.vB0 = ld_d2<0>(val + jB_);                                                      \
         R.vB1 = ld_d2<0>(val + jB_ + 2);                                                  \
         R.rp = rp[jr_];                                                                   \
     } while (0)
+    // four packed dictionary indices -> four (col - row) offsets
+#define S4_DECODE(w)                                                                      \
+    make_int4(s_dict[(unsigned)(w) & 255u], s_dict[((unsigned)(w) >> 8) & 255u],          \
+              s_dict[((unsigned)(w) >> 16) & 255u], s_dict[(unsigned)(w) >> 24])
 #define S4_COMMIT(R, d, buf)                                                              \
     do {                                                                                  \
         const int base_ = (d).z & ~3;                                                     \
         const int oA_ = 4 * t, oB_ = oA_ + 4 * ITS_BLOCK;                                 \
         const int nr_ = (d).y & 0xffff;                                                   \
         if (base_ + oA_ < (d).w) {                                                        \
-            *reinterpret_cast<int4 *>(&s_col[buf][oA_]) = R.cA;                           \
+            *reinterpret_cast<int4 *>(&s_col[buf][oA_]) = IDX ? S4_DECODE(R.cA.x) : R.cA; \
             *reinterpret_cast<double2 *>(&s_val[buf][oA_]) = R.vA0;                       \
             *reinterpret_cast<double2 *>(&s_val[buf][oA_ + 2]) = R.vA1;                   \
         }                                                                                 \
         if (base_ + oB_ < (d).w) {                                                        \
-            *reinterpret_cast<int4 *>(&s_col[buf][oB_]) = R.cB;                           \
+            *reinterpret_cast<int4 *>(&s_col[buf][oB_]) = IDX ? S4_DECODE(R.cB.x) : R.cB; \
             *reinterpret_cast<double2 *>(&s_val[buf][oB_]) = R.vB0;                       \
             *reinterpret_cast<double2 *>(&s_val[buf][oB_ + 2]) = R.vB1;                   \
         }                                                                                 \
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         const bool ok_ = j + u < j1;                                                      \
         const int jj_ = ok_ ? j + u : 0;                                                  \
         const int cc_ = s_col[buf][jj_];                                                  \
-        c[u] = ok_ ? cc_ : 0; v[u] = s_val[buf][jj_];                                     \
+        c[u] = ok_ ? (IDX ? row + cc_ : cc_) : 0; v[u] = s_val[buf][jj_];                 \
     }                                                                                     \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
 #define S4_BATCH_FMA()                                                                    \
@@ -517,6 +526,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
     }
 #undef S4_DESC
 #undef S4_ISSUE
+#undef S4_DECODE
 #undef S4_COMMIT
 #undef S4_BATCH_LOAD
 #undef S4_BATCH_FMA
@@ -728,6 +738,7 @@ static int env_int(const char *name, int dflt)
 static int g_spmv_variant = env_int("ITS_SPMV_VARIANT", 4);
 static int g_spmv_grid = env_int("ITS_SPMV_GRID", g_spmv_variant == 4 ? 512 : 1024);
 static int g_spmv_map = env_int("ITS_SPMV_MAP", 1);
+static int g_spmv_idx = env_int("ITS_SPMV_IDX", 1);             // 0 = never use the 1-byte column-offset stream
 static int g_spmv_irr = env_int("ITS_SPMV_IRR", 1);             // 0 = never use the irregular-row kernel
 static int g_spmv_irr_grid = env_int("ITS_SPMV_IRR_GRID", 1280);
 static int g_spmv_nt = env_int("ITS_SPMV_NT", 0);
@@ -736,6 +747,7 @@ int spmv_tune(const char *name, int value)
     if (!strcmp(name, "spmv_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_grid = value; return 0; }
     if (!strcmp(name, "spmv_map")) { if (value < 0 || value > 1) return -1; g_spmv_map = value; return 0; }
     if (!strcmp(name, "spmv_variant")) { if (value != 1 && value != 2 && value != 4) return -1; g_spmv_variant = value; return 0; }
+    if (!strcmp(name, "spmv_idx")) { if (value < 0 || value > 1) return -1; g_spmv_idx = value; return 0; }
     if (!strcmp(name, "spmv_irr")) { if (value < 0 || value > 1) return -1; g_spmv_irr = value; return 0; }
     if (!strcmp(name, "spmv_irr_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_irr_grid = value; return 0; }
     if (!strcmp(name, "spmv_nt")) { if (value < 0 || value > 3) return -1; g_spmv_nt = value; return 0; }
@@ -778,8 +790,15 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
 #undef ITS_LAUNCHI
         return;
     }
-#define ITS_LAUNCH4(E, D) \
-    hipLaunchKernelGGL((spmv_stream4_kernel<E, D>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
+#define ITS_LAUNCH4(E, D)                                                                                     \
+    do {                                                                                                      \
+        if (A.n_off > 0 && g_spmv_idx)                                                                        \
+            hipLaunchKernelGGL((spmv_stream4_kernel<E, D, true>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, \
+                               A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
+        else                                                                                                  \
+            hipLaunchKernelGGL((spmv_stream4_kernel<E, D, false>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, \
+                               A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
+    } while (0)
     if (g_spmv_variant == 4) {
         switch (epi) {
         case EPI_STORE: if (a.dotv) ITS_LAUNCH4(EPI_STORE, true); else ITS_LAUNCH4(EPI_STORE, false); break;

@@ -67,6 +67,23 @@ def test_spmv_both_exact_kernels(gpu_handle):
         gpu_handle.set_option("spmv_irr", 1)
 
 
+@pytest.mark.parametrize("name", ["lap2d_64", "lap3d_16", "cd27_12"])
+def test_spmv_offset_dictionary_stream(gpu_handle, name):
+    """Stencil-class matrices (<= 256 distinct col - row) stream a 1-byte offset index instead of the
+    4-byte column: same arithmetic, so bit-exact with and without it."""
+    rp, col, val = MATRICES[name]()
+    n = len(rp) - 1
+    x = np.random.default_rng(4).uniform(-1, 1, n)
+    ref = orc.spmv(rp, col, val, x)
+    gpu_handle.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+    try:
+        for idx in (0, 1):
+            gpu_handle.set_option("spmv_idx", idx)
+            assert np.array_equal(gpu_handle.spmv_host(x, n, capi.MAT_A, capi.FMT_CSR_EXACT), ref), idx
+    finally:
+        gpu_handle.set_option("spmv_idx", 1)
+
+
 def test_spmv_known_answers(gpu_handle):
     """M1*V1 = {74,134,194}, Mn*V1 = {-58,-22,-76.2} (reference test_suite/test_data.cpp:40-49,4-13,467-494)."""
     import json, os
