@@ -15,7 +15,7 @@
 static void free_csr(CsrDev &A)
 {
     dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_row); dfree(A.blk_desc);
-    dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict);
+    dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict); dfree(A.vidx); dfree(A.val_dict);
     A = CsrDev();
 }
 
@@ -219,6 +219,30 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
             if (dalloc(h, &A.cidx, cidx.size()) || dalloc(h, &A.off_dict, 256)) return ITS_EHIP;
             HIPCHK(h, hipMemcpy(A.cidx, cidx.data(), cidx.size(), hipMemcpyHostToDevice));
             HIPCHK(h, hipMemcpy(A.off_dict, dict.data(), 256 * sizeof(int), hipMemcpyHostToDevice));
+        }
+        // value dictionary: at most 256 distinct fp64 bit patterns (constant-coefficient stencils)
+        if (ok) {
+            std::vector<uint64_t> keys(1024, 0); std::vector<int16_t> ids(1024, (int16_t)-1);
+            std::vector<double> vd;
+            std::vector<unsigned char> &vidx = cidx;                   // reuse the host buffer
+            bool vok = true;
+            for (int64_t k = 0; k < nnz && vok; ++k) {
+                uint64_t bits; memcpy(&bits, &val[k], 8);
+                size_t p = (size_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);
+                while (ids[p] >= 0 && keys[p] != bits) p = (p + 1) & 1023;
+                if (ids[p] < 0) {
+                    if (vd.size() == 256) { vok = false; break; }
+                    ids[p] = (int16_t)vd.size(); keys[p] = bits; vd.push_back(val[k]);
+                }
+                vidx[k] = (unsigned char)ids[p];
+            }
+            if (vok) {
+                A.n_vals = (int)vd.size();
+                vd.resize(256, 0.0);
+                if (dalloc(h, &A.vidx, vidx.size()) || dalloc(h, &A.val_dict, 256)) return ITS_EHIP;
+                HIPCHK(h, hipMemcpy(A.vidx, vidx.data(), vidx.size(), hipMemcpyHostToDevice));
+                HIPCHK(h, hipMemcpy(A.val_dict, vd.data(), 256 * sizeof(double), hipMemcpyHostToDevice));
+            }
         }
     }
     std::vector<int> blk;

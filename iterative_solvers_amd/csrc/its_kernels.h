@@ -37,6 +37,10 @@ struct CsrDev {
     unsigned char *cidx = nullptr;
     int *off_dict = nullptr;                  // [256]
     int n_off = 0;                            // 0 = not eligible
+    // value dictionary (opt-in, option "spmv_valdict"): at most 256 distinct fp64 bit patterns in val
+    unsigned char *vidx = nullptr;
+    double *val_dict = nullptr;               // [256]
+    int n_vals = 0;                           // 0 = not eligible
     // stream plan
     int n_blocks = 0;
     int *blk_row = nullptr;

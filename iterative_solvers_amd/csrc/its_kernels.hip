@@ -345,12 +345,18 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
 // --------------------------------------------------------------------------------------
 struct StageRegs { int4 cA, cB; double2 vA0, vA1, vB0, vB1; int rp; };
 
-template <int EPI, bool DOT, bool IDX>
+// CMP: 0 = plain col/val streams (12 B per nonzero); 1 = 1-byte column-offset index + val (9 B);
+//      2 = 1-byte offset index + 1-byte value index (2 B; opt-in, matrices with <= 256 distinct values).
+// Both dictionaries are lossless: the decoded column and the decoded fp64 value are the CRS entries bit for bit.
+template <int EPI, bool DOT, int CMP>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
     int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
     const int *__restrict__ col, const double *__restrict__ val, int n_rows,
-    const unsigned char *__restrict__ cidx, const int *__restrict__ off_dict, SpmvArgs a)
+    const unsigned char *__restrict__ cidx, const int *__restrict__ off_dict,
+    const unsigned char *__restrict__ vidx, const double *__restrict__ val_dict, SpmvArgs a)
 {
+    constexpr bool IDX = CMP >= 1, VD = CMP == 2;
+    __shared__ double s_vdict[VD ? 256 : 1];
     __shared__ __attribute__((aligned(16))) double s_val[2][S2_CAP];
     __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];    // IDX: col - row, decoded at commit
     __shared__ int s_rp[2][ITS_BLOCK + 4];
@@ -359,7 +365,11 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
 
     const int t = threadIdx.x;
     const int G = gridDim.x;
-    if (IDX) { s_dict[t] = off_dict[t]; __syncthreads(); }
+    if (IDX) {
+        s_dict[t] = off_dict[t];
+        if (VD) s_vdict[t] = val_dict[t];
+        __syncthreads();
+    }
     int rb0, rb1, rstep;
     if (a.map_mode == 0) {
         const int slot = xcd_slot(blockIdx.x, G);
@@ -387,18 +397,20 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         const int jr_ = t < ((d).y & 0xffff) ? (d).x + t : 0;                             \
         if (IDX) R.cA.x = *reinterpret_cast<const int *>(cidx + jA_);                     \
         else R.cA = ld_i4<0>(col + jA_);                                                  \
-        R.vA0 = ld_d2<0>(val + jA_);                                                      \
-        R.vA1 = ld_d2<0>(val + jA_ + 2);                                                  \
+        if (VD) R.cA.y = *reinterpret_cast<const int *>(vidx + jA_);                      \
+        else { R.vA0 = ld_d2<0>(val + jA_); R.vA1 = ld_d2<0>(val + jA_ + 2); }            \
         if (IDX) R.cB.x = *reinterpret_cast<const int *>(cidx + jB_);                     \
         else R.cB = ld_i4<0>(col + jB_);                                                  \
-        R.vB0 = ld_d2<0>(val + jB_);                                                      \
-        R.vB1 = ld_d2<0>(val + jB_ + 2);                                                  \
+        if (VD) R.cB.y = *reinterpret_cast<const int *>(vidx + jB_);                      \
+        else { R.vB0 = ld_d2<0>(val + jB_); R.vB1 = ld_d2<0>(val + jB_ + 2); }            \
         R.rp = rp[jr_];                                                                   \
     } while (0)
     // four packed dictionary indices -> four (col - row) offsets
 #define S4_DECODE(w)                                                                      \
     make_int4(s_dict[(unsigned)(w) & 255u], s_dict[((unsigned)(w) >> 8) & 255u],          \
               s_dict[((unsigned)(w) >> 16) & 255u], s_dict[(unsigned)(w) >> 24])
+#define S4_VDEC0(w) make_double2(s_vdict[(unsigned)(w) & 255u], s_vdict[((unsigned)(w) >> 8) & 255u])
+#define S4_VDEC1(w) make_double2(s_vdict[((unsigned)(w) >> 16) & 255u], s_vdict[(unsigned)(w) >> 24])
 #define S4_COMMIT(R, d, buf)                                                              \
     do {                                                                                  \
         const int base_ = (d).z & ~3;                                                     \
@@ -406,13 +418,13 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         const int nr_ = (d).y & 0xffff;                                                   \
         if (base_ + oA_ < (d).w) {                                                        \
             *reinterpret_cast<int4 *>(&s_col[buf][oA_]) = IDX ? S4_DECODE(R.cA.x) : R.cA; \
-            *reinterpret_cast<double2 *>(&s_val[buf][oA_]) = R.vA0;                       \
-            *reinterpret_cast<double2 *>(&s_val[buf][oA_ + 2]) = R.vA1;                   \
+            *reinterpret_cast<double2 *>(&s_val[buf][oA_]) = VD ? S4_VDEC0(R.cA.y) : R.vA0;     \
+            *reinterpret_cast<double2 *>(&s_val[buf][oA_ + 2]) = VD ? S4_VDEC1(R.cA.y) : R.vA1; \
         }                                                                                 \
         if (base_ + oB_ < (d).w) {                                                        \
             *reinterpret_cast<int4 *>(&s_col[buf][oB_]) = IDX ? S4_DECODE(R.cB.x) : R.cB; \
-            *reinterpret_cast<double2 *>(&s_val[buf][oB_]) = R.vB0;                       \
-            *reinterpret_cast<double2 *>(&s_val[buf][oB_ + 2]) = R.vB1;                   \
+            *reinterpret_cast<double2 *>(&s_val[buf][oB_]) = VD ? S4_VDEC0(R.cB.y) : R.vB0;     \
+            *reinterpret_cast<double2 *>(&s_val[buf][oB_ + 2]) = VD ? S4_VDEC1(R.cB.y) : R.vB1; \
         }                                                                                 \
         if (t < nr_) s_rp[buf][t] = R.rp;                                                 \
         if (t == 0) s_rp[buf][nr_] = (d).w;                                               \
@@ -527,6 +539,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
 #undef S4_DESC
 #undef S4_ISSUE
 #undef S4_DECODE
+#undef S4_VDEC0
+#undef S4_VDEC1
 #undef S4_COMMIT
 #undef S4_BATCH_LOAD
 #undef S4_BATCH_FMA
@@ -739,6 +753,8 @@ static int g_spmv_variant = env_int("ITS_SPMV_VARIANT", 4);
 static int g_spmv_grid = env_int("ITS_SPMV_GRID", g_spmv_variant == 4 ? 512 : 1024);
 static int g_spmv_map = env_int("ITS_SPMV_MAP", 1);
 static int g_spmv_idx = env_int("ITS_SPMV_IDX", 1);             // 0 = never use the 1-byte column-offset stream
+static int g_spmv_valdict = env_int("ITS_SPMV_VALDICT", 0);     // opt-in: 1-byte value-dictionary stream
+static int g_spmv_vd_grid = env_int("ITS_SPMV_VD_GRID", 768);   // its grid (3 workgroups per CU measured best)
 static int g_spmv_irr = env_int("ITS_SPMV_IRR", 1);             // 0 = never use the irregular-row kernel
 static int g_spmv_irr_grid = env_int("ITS_SPMV_IRR_GRID", 1280);
 static int g_spmv_nt = env_int("ITS_SPMV_NT", 0);
@@ -748,6 +764,7 @@ int spmv_tune(const char *name, int value)
     if (!strcmp(name, "spmv_map")) { if (value < 0 || value > 1) return -1; g_spmv_map = value; return 0; }
     if (!strcmp(name, "spmv_variant")) { if (value != 1 && value != 2 && value != 4) return -1; g_spmv_variant = value; return 0; }
     if (!strcmp(name, "spmv_idx")) { if (value < 0 || value > 1) return -1; g_spmv_idx = value; return 0; }
+    if (!strcmp(name, "spmv_valdict")) { if (value < 0 || value > 1) return -1; g_spmv_valdict = value; return 0; }
     if (!strcmp(name, "spmv_irr")) { if (value < 0 || value > 1) return -1; g_spmv_irr = value; return 0; }
     if (!strcmp(name, "spmv_irr_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_irr_grid = value; return 0; }
     if (!strcmp(name, "spmv_nt")) { if (value < 0 || value > 3) return -1; g_spmv_nt = value; return 0; }
@@ -792,12 +809,15 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
     }
 #define ITS_LAUNCH4(E, D)                                                                                     \
     do {                                                                                                      \
-        if (A.n_off > 0 && g_spmv_idx)                                                                        \
-            hipLaunchKernelGGL((spmv_stream4_kernel<E, D, true>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, \
-                               A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
+        if (A.n_off > 0 && g_spmv_idx && A.n_vals > 0 && g_spmv_valdict)                                      \
+            hipLaunchKernelGGL((spmv_stream4_kernel<E, D, 2>), dim3(g_spmv_vd_grid), b, 0, s, n_desc, desc, A.row_ptr, A.col,   \
+                               A.val, A.n_rows, A.cidx, A.off_dict, A.vidx, A.val_dict, a);                   \
+        else if (A.n_off > 0 && g_spmv_idx)                                                                   \
+            hipLaunchKernelGGL((spmv_stream4_kernel<E, D, 1>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col,   \
+                               A.val, A.n_rows, A.cidx, A.off_dict, A.vidx, A.val_dict, a);                   \
         else                                                                                                  \
-            hipLaunchKernelGGL((spmv_stream4_kernel<E, D, false>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, \
-                               A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
+            hipLaunchKernelGGL((spmv_stream4_kernel<E, D, 0>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col,   \
+                               A.val, A.n_rows, A.cidx, A.off_dict, A.vidx, A.val_dict, a);                   \
     } while (0)
     if (g_spmv_variant == 4) {
         switch (epi) {

@@ -77,11 +77,13 @@ def test_spmv_offset_dictionary_stream(gpu_handle, name):
     ref = orc.spmv(rp, col, val, x)
     gpu_handle.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
     try:
-        for idx in (0, 1):
+        for idx, vd in ((0, 0), (1, 0), (1, 1)):
             gpu_handle.set_option("spmv_idx", idx)
-            assert np.array_equal(gpu_handle.spmv_host(x, n, capi.MAT_A, capi.FMT_CSR_EXACT), ref), idx
+            gpu_handle.set_option("spmv_valdict", vd)       # opt-in 1-byte value dictionary (<= 256 distinct values)
+            assert np.array_equal(gpu_handle.spmv_host(x, n, capi.MAT_A, capi.FMT_CSR_EXACT), ref), (idx, vd)
     finally:
         gpu_handle.set_option("spmv_idx", 1)
+        gpu_handle.set_option("spmv_valdict", 0)
 
 
 def test_spmv_known_answers(gpu_handle):
