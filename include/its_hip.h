@@ -71,7 +71,15 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                  1 = the reference's formulation product for product (dense (m+1)^2 products
  *                      J, Q <- J Q, R = Q H, g = Q beta e1, methods/gmres.hpp:427-658): O(m^3) host
  *                      work per trip, reproduces the reference's |g[k+1]| also BELOW the attainable
- *                      accuracy, where the rotation form keeps shrinking and the dense form stalls. */
+ *                      accuracy, where the rotation form keeps shrinking and the dense form stalls.
+ * Process-wide launch options of the exact SpMV (any time; all lossless, results bit-identical):
+ *   "spmv_idx"     1 (default) = stream the 1-byte column-offset dictionary index instead of the 4-byte
+ *                  column when the matrix has <= 256 distinct col - row; 0 = always the plain col stream
+ *   "spmv_valdict" 1 = also stream values as 1-byte dictionary indices (<= 256 distinct fp64 values);
+ *                  default 0
+ *   "spmv_irr"     1 (default) = two-phase kernel when the longest row exceeds 32 entries
+ *   "spmv_variant" 4 (default) | 2 | 1, "spmv_grid", "spmv_irr_grid", "spmv_map" 0|1, "spmv_nt" 0..3:
+ *                  tuning knobs kept for A/B measurements (tools/spmv_ab.py) */
 int its_set_option(its_handle *h, const char *name, int value);
 
 /* ---- the loop body (solver_harness.hpp:40-116) -------------------------------------- */
