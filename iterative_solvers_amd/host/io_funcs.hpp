@@ -7,6 +7,7 @@
 #include <iostream>
 #include <numeric>
 #include "structs.hpp"
+#include "mtx_fast.hpp"
 
 inline void assign_cli_inputs(argType *args, int argc, char *argv[])
 {
@@ -45,6 +46,10 @@ inline void assign_cli_inputs(argType *args, int argc, char *argv[])
 // mirrored right behind their original; stable sort by row keeps the file order inside a row
 inline void read_mtx(const std::string &file, COOMtxData *coo)
 {
+    // parallel parser / binary cache first (mtx_fast.hpp: the same COO, faster); ITS_MTX_READER=fscanf
+    // forces the loop below, which is also where every malformed file ends up and gets its error message
+    const char *rd = getenv("ITS_MTX_READER");
+    if (!(rd && !strcmp(rd, "fscanf")) && mtx_fast::read(file, coo)) return;
     FILE *f = fopen(file.c_str(), "r");
     if (!f) { printf("Unable to open file"); exit(1); }
     char line[1100], banner[64], obj[64], fmt[64], field[64], symm[64];

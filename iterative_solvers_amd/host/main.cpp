@@ -56,6 +56,16 @@ void run_solver(int argc, char *argv[])
 
 int main(int argc, char *argv[])
 {
+    if (argc == 3 && std::string(argv[1]) == "--parse-only") {
+        // its_solve --parse-only file.mtx : read the matrix (no GPU needed), print its shape, an
+        // order-sensitive checksum of the row-sorted COO and the time (tests, reader comparisons)
+        COOMtxData coo;
+        Stopwatch sw; sw.start_stopwatch();
+        read_mtx(argv[2], &coo);
+        sw.end_stopwatch();
+        printf("%ld %ld %ld %016llx %.3f\n", coo.n_rows, coo.n_cols, coo.nnz, (unsigned long long)mtx_fast::checksum(coo), sw.get_wtime());
+        return 0;
+    }
     run_solver<double>(argc, argv);
     return 0;
 }
