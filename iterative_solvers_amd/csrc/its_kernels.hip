@@ -143,18 +143,23 @@ template <int NT> __device__ __forceinline__ void st_d1(double *p, double v)
     if (NT & 2) __builtin_nontemporal_store(v, p); else *p = v;
 }
 
-template <int EPI, bool DOT, int NT>
+// IDX: stream the 1-byte column-offset dictionary index instead of col (see spmv_stream4_kernel, CMP = 1)
+template <int EPI, bool DOT, bool IDX>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
     int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
-    const int *__restrict__ col, const double *__restrict__ val, int n_rows, SpmvArgs a)
+    const int *__restrict__ col, const double *__restrict__ val, int n_rows,
+    const unsigned char *__restrict__ cidx, const int *__restrict__ off_dict, SpmvArgs a)
 {
+    constexpr int NT = 0;
     __shared__ __attribute__((aligned(16))) double s_val[2][S2_CAP];
-    __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];
+    __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];    // IDX: col - row, decoded at commit
     __shared__ int s_rp[2][ITS_BLOCK + 4];
+    __shared__ int s_dict[IDX ? 256 : 1];
     __shared__ double s_red[4];
 
     const int t = threadIdx.x;
     const int G = gridDim.x;
+    if (IDX) { s_dict[t] = off_dict[t]; __syncthreads(); }
     int rb0, rb1, rstep;
     if (a.map_mode == 0) {
         const int slot = xcd_slot(blockIdx.x, G);
@@ -181,28 +186,33 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         const int base_ = (d).z & ~3;                                                     \
         const int iA_ = base_ + 4 * t, iB_ = iA_ + 4 * ITS_BLOCK;                         \
         if (iA_ < (d).w) {                                                                \
-            rcA = ld_i4<NT & 1>(col + iA_);                                               \
+            if (IDX) rcA.x = *reinterpret_cast<const int *>(cidx + iA_);                  \
+            else rcA = ld_i4<NT & 1>(col + iA_);                                          \
             rvA0 = ld_d2<NT & 1>(val + iA_);                                              \
             rvA1 = ld_d2<NT & 1>(val + iA_ + 2);                                          \
         }                                                                                 \
         if (iB_ < (d).w) {                                                                \
-            rcB = ld_i4<NT & 1>(col + iB_);                                               \
+            if (IDX) rcB.x = *reinterpret_cast<const int *>(cidx + iB_);                  \
+            else rcB = ld_i4<NT & 1>(col + iB_);                                          \
             rvB0 = ld_d2<NT & 1>(val + iB_);                                              \
             rvB1 = ld_d2<NT & 1>(val + iB_ + 2);                                          \
         }                                                                                 \
         if (t < (d).y) rrp = ld_i1<NT & 1>(rp + (d).x + t);                               \
     } while (0)
+#define S2_DECODE(w)                                                                      \
+    make_int4(s_dict[(unsigned)(w) & 255u], s_dict[((unsigned)(w) >> 8) & 255u],          \
+              s_dict[((unsigned)(w) >> 16) & 255u], s_dict[(unsigned)(w) >> 24])
 #define S2_COMMIT(d, buf)                                                                 \
     do {                                                                                  \
         const int base_ = (d).z & ~3;                                                     \
         const int oA_ = 4 * t, oB_ = oA_ + 4 * ITS_BLOCK;                                 \
         if (base_ + oA_ < (d).w) {                                                        \
-            *reinterpret_cast<int4 *>(&s_col[buf][oA_]) = rcA;                            \
+            *reinterpret_cast<int4 *>(&s_col[buf][oA_]) = IDX ? S2_DECODE(rcA.x) : rcA;   \
             *reinterpret_cast<double2 *>(&s_val[buf][oA_]) = rvA0;                        \
             *reinterpret_cast<double2 *>(&s_val[buf][oA_ + 2]) = rvA1;                    \
         }                                                                                 \
         if (base_ + oB_ < (d).w) {                                                        \
-            *reinterpret_cast<int4 *>(&s_col[buf][oB_]) = rcB;                            \
+            *reinterpret_cast<int4 *>(&s_col[buf][oB_]) = IDX ? S2_DECODE(rcB.x) : rcB;   \
             *reinterpret_cast<double2 *>(&s_val[buf][oB_]) = rvB0;                        \
             *reinterpret_cast<double2 *>(&s_val[buf][oB_ + 2]) = rvB1;                    \
         }                                                                                 \
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int jj = (j + u < j1) ? j + u : j;
-                        c[u] = s_col[cur][jj]; v[u] = s_val[cur][jj];
+                        c[u] = IDX ? row + s_col[cur][jj] : s_col[cur][jj]; v[u] = s_val[cur][jj];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
@@ -302,6 +312,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         d = dn; dn = dnn;
     }
 #undef S2_ISSUE
+#undef S2_DECODE
 #undef S2_COMMIT
     if (DOT || EPI == EPI_RESIDUAL) {
         const double bs = block_sum(lane_sum, s_red);
@@ -775,22 +786,21 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
                             int accumulate, hipStream_t s)
 {
     int g2v = g_spmv_grid;
+    const int g2v_long = g_spmv_variant == 4 ? 1024 : g2v;   // v2's own best grid (4 workgroups per CU)
     const int mm = g_spmv_map;
     if (g2v < 8 || g2v > ITS_NPART || (g2v & 7)) g2v = 1024;
     dim3 g2(g2v), b(ITS_BLOCK);
     SpmvArgs a = a_in;
     a.map_mode = mm;
     a.part_accum = accumulate;
-#define ITS_LAUNCH2N(E, D, N) \
-    hipLaunchKernelGGL((spmv_stream2_kernel<E, D, N>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
-#define ITS_LAUNCH2(E, D)                                                          \
-    do {                                                                           \
-        switch (g_spmv_nt) {                                                       \
-        case 1: ITS_LAUNCH2N(E, D, 1); break;                                      \
-        case 2: ITS_LAUNCH2N(E, D, 2); break;                                      \
-        case 3: ITS_LAUNCH2N(E, D, 3); break;                                      \
-        default: ITS_LAUNCH2N(E, D, 0); break;                                     \
-        }                                                                          \
+#define ITS_LAUNCH2(E, D)                                                                                     \
+    do {                                                                                                      \
+        if (A.n_off > 0 && g_spmv_idx)                                                                        \
+            hipLaunchKernelGGL((spmv_stream2_kernel<E, D, true>), dim3(g2v_long), b, 0, s, n_desc, desc, A.row_ptr, A.col, \
+                               A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
+        else                                                                                                  \
+            hipLaunchKernelGGL((spmv_stream2_kernel<E, D, false>), dim3(g2v_long), b, 0, s, n_desc, desc, A.row_ptr, A.col, \
+                               A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
     } while (0)
     // irregular rows: the two-phase kernel (5 workgroups per CU by its LDS footprint)
     if (A.max_row_len > IRR_ROW_LEN && g_spmv_variant != 1 && g_spmv_irr) {
@@ -819,7 +829,9 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
             hipLaunchKernelGGL((spmv_stream4_kernel<E, D, 0>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col,   \
                                A.val, A.n_rows, A.cidx, A.off_dict, A.vidx, A.val_dict, a);                   \
     } while (0)
-    if (g_spmv_variant == 4) {
+    // v4 keeps one batch of 8 gathers per row in flight; rows of 9..32 entries (27-pt) run faster in v2,
+    // whose per-lane batch loop does not wait for the longest row of the block (0.169 vs 0.213 ms, 27-pt 128^3)
+    if (g_spmv_variant == 4 && A.max_row_len <= 8) {
         switch (epi) {
         case EPI_STORE: if (a.dotv) ITS_LAUNCH4(EPI_STORE, true); else ITS_LAUNCH4(EPI_STORE, false); break;
         case EPI_RESIDUAL: ITS_LAUNCH4(EPI_RESIDUAL, false); break;
@@ -838,7 +850,6 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
     case EPI_GS_RHS: ITS_LAUNCH2(EPI_GS_RHS, false); break;
     }
 #undef ITS_LAUNCH2
-#undef ITS_LAUNCH2N
 }
 
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)

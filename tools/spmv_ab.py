@@ -12,8 +12,13 @@ N = int(os.environ.get("N", "256"))
 REPS = int(os.environ.get("REPS", "40"))
 ROUNDS = int(os.environ.get("ROUNDS", "2"))
 NZ = int(os.environ.get("NZ", "0")) or None
-rp, col, val = matgen.laplace3d_7pt(N, NZ)
-print("grid %d x %d x %d" % (N, N, NZ or N), flush=True)
+MAT = os.environ.get("MAT", "lap7")
+if MAT == "cd27":
+    rp, col, val = matgen.convdiff3d_27pt(N)
+    print("27-pt convection-diffusion %d^3" % N, flush=True)
+else:
+    rp, col, val = matgen.laplace3d_7pt(N, NZ)
+    print("grid %d x %d x %d" % (N, N, NZ or N), flush=True)
 n, nnz = len(rp) - 1, len(col)
 by = 12 * nnz + 4 * (n + 1) + 16 * n
 h = capi.Handle(0)
