@@ -768,6 +768,7 @@ static int g_spmv_valdict = env_int("ITS_SPMV_VALDICT", 0);     // opt-in: 1-byt
 static int g_spmv_vd_grid = env_int("ITS_SPMV_VD_GRID", 768);   // its grid (3 workgroups per CU measured best)
 static int g_spmv_irr = env_int("ITS_SPMV_IRR", 1);             // 0 = never use the irregular-row kernel
 static int g_spmv_irr_grid = env_int("ITS_SPMV_IRR_GRID", 1280);
+static int g_spmv_irr_len = env_int("ITS_SPMV_IRR_LEN", IRR_ROW_LEN);   // longest row above which it is used
 static int g_spmv_nt = env_int("ITS_SPMV_NT", 0);
 int spmv_tune(const char *name, int value)
 {
@@ -777,6 +778,7 @@ int spmv_tune(const char *name, int value)
     if (!strcmp(name, "spmv_idx")) { if (value < 0 || value > 1) return -1; g_spmv_idx = value; return 0; }
     if (!strcmp(name, "spmv_valdict")) { if (value < 0 || value > 1) return -1; g_spmv_valdict = value; return 0; }
     if (!strcmp(name, "spmv_irr")) { if (value < 0 || value > 1) return -1; g_spmv_irr = value; return 0; }
+    if (!strcmp(name, "spmv_irr_len")) { if (value < 1) return -1; g_spmv_irr_len = value; return 0; }
     if (!strcmp(name, "spmv_irr_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_irr_grid = value; return 0; }
     if (!strcmp(name, "spmv_nt")) { if (value < 0 || value > 3) return -1; g_spmv_nt = value; return 0; }
     return -2;
@@ -803,7 +805,7 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
                                A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
     } while (0)
     // irregular rows: the two-phase kernel (5 workgroups per CU by its LDS footprint)
-    if (A.max_row_len > IRR_ROW_LEN && g_spmv_variant != 1 && g_spmv_irr) {
+    if (A.max_row_len > g_spmv_irr_len && g_spmv_variant != 1 && g_spmv_irr) {
         dim3 gi(g_spmv_irr_grid);
 #define ITS_LAUNCHI(E, D) \
     hipLaunchKernelGGL((spmv_irr_kernel<E, D>), gi, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
