@@ -544,7 +544,8 @@ static int trip_jacobi(its_handle *h, double *res_out)
     }
     if (rc) return rc;
     // record_residual_norm: r = b - A x_new, 2-norm (utility_funcs.hpp:423-426)
-    SpmvArgs q; q.x = h->x_b; q.y = h->r; q.b = h->b; q.part_sum = h->part[0];
+    // (only the norm is recorded: the residual vector itself is not stored, y = nullptr)
+    SpmvArgs q; q.x = h->x_b; q.y = nullptr; q.b = h->b; q.part_sum = h->part[0];
     if ((rc = solver_spmv(h, q, EPI_RESIDUAL))) return rc;
     if ((rc = finish_scalar(h, h->part[0], res_out, FIN_SQRT))) return rc;
     std::swap(h->x_a, h->x_b);                                        // exchange_arrays
@@ -557,7 +558,7 @@ static int trip_gs(its_handle *h, double *res_out)
     int rc = spmv_dispatch(h, h->mat[ITS_MAT_U], u, EPI_GS_RHS, ITS_FMT_CSR_EXACT);   // gauss_seidel.hpp:144,177
     if (rc) return rc;
     if ((rc = sweep(h, h->x, h->tmp))) return rc;                                      // :227
-    SpmvArgs q; q.x = h->x; q.y = h->r; q.b = h->b; q.part_sum = h->part[0];
+    SpmvArgs q; q.x = h->x; q.y = nullptr; q.b = h->b; q.part_sum = h->part[0];         // norm only
     if ((rc = solver_spmv(h, q, EPI_RESIDUAL))) return rc;                             // utility_funcs.hpp:444-447
     return finish_scalar(h, h->part[0], res_out, FIN_SQRT);
 }

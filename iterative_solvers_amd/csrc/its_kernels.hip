@@ -79,7 +79,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream_kernel(
                 if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
             } else if (EPI == EPI_RESIDUAL) {
                 const double r = a.b[row] - acc;
-                a.y[row] = r;
+                if (a.y) a.y[row] = r;                       // y == nullptr: only the norm is wanted
                 lane_sum = fma(r, r, lane_sum);
                 lane_max = fmax(lane_max, fabs(r));
             } else if (EPI == EPI_JACOBI_SHIPPED) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
                 if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
             } else if (EPI == EPI_RESIDUAL) {
                 const double r = a.b[row] - acc;
-                st_d1<NT>(a.y + row, r);
+                if (a.y) st_d1<NT>(a.y + row, r);
                 lane_sum = fma(r, r, lane_sum);
                 lane_max = fmax(lane_max, fabs(r));
             } else if (EPI == EPI_JACOBI_SHIPPED) {
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
             } else {                                                                                      \
                 outv = fma(-1.0, acc, e0);                                                                \
             }                                                                                             \
-            pend_val = outv; pend_row = row;                                                              \
+            if (a.y) { pend_val = outv; pend_row = row; }   /* y == nullptr: only the norm is wanted */   \
         }                                                                                                 \
         dA = dB; dB = dC; dC = dD;                                                                        \
         ++it;                                                                                             \
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_irr_kernel(
                 if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
             } else if (EPI == EPI_RESIDUAL) {
                 const double r = a.b[row] - acc;
-                a.y[row] = r;
+                if (a.y) a.y[row] = r;                       // y == nullptr: only the norm is wanted
                 lane_sum = fma(r, r, lane_sum);
                 lane_max = fmax(lane_max, fabs(r));
             } else if (EPI == EPI_JACOBI_SHIPPED) {
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_vector_kernel(
                 if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
             } else if (EPI == EPI_RESIDUAL) {
                 const double r = a.b[row] - acc;
-                a.y[row] = r;
+                if (a.y) a.y[row] = r;                       // y == nullptr: only the norm is wanted
                 lane_sum = fma(r, r, lane_sum);
                 lane_max = fmax(lane_max, fabs(r));
             }
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_sell_kernel(
                 if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);                      \
             } else if (EPI == EPI_RESIDUAL) {                                             \
                 const double r = a.b[row] - acc;                                          \
-                a.y[row] = r;                                                             \
+                if (a.y) a.y[row] = r;                                                    \
                 lane_sum = fma(r, r, lane_sum);                                           \
                 lane_max = fmax(lane_max, fabs(r));                                       \
             }                                                                             \
