@@ -175,8 +175,8 @@ def main():
             k_ms = inloop_spmv_ms
             ach = spmv_bytes(n, nnz) / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic("spmv_stream4_kernel<0, true,") if (fmt == capi.FMT_CSR_EXACT and world == 1 and N == 256) else None,
-                    "kernel": "its::spmv_stream4_kernel<0, true, true> (CSR SpMV + fused p.Ap partials, 1-byte offset stream)" if fmt == capi.FMT_CSR_EXACT else a.format,
+                    "traffic": pmc_traffic("spmv_stream4_kernel<0, true, 1>") if (fmt == capi.FMT_CSR_EXACT and world == 1 and N == 256) else None,
+                    "kernel": "its::spmv_stream4_kernel<0, true, 1> (CSR SpMV + fused p.Ap partials, 1-byte offset stream)" if fmt == capi.FMT_CSR_EXACT else a.format,
                     "kernel_ms": k_ms, "algorithmic_bytes": spmv_bytes(n, nnz),
                     # what the kernel is asked to move: the 7-pt matrix has 7 distinct col-row offsets, so the
                     # exact kernel streams a 1-byte offset index instead of the 4-byte column (lossless)
