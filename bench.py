@@ -114,7 +114,10 @@ def main():
     host_transport = os.environ.get("ITS_BENCH_TRANSPORT", "rccl") == "host"
     sol = S.Solver("conjugate-gradient", device=0 if host_transport else local_rank, spmv_format=fmt)
     h = sol.handle
-    if world == 1:
+    # ITS_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL communicators, split SpMV, all-reduced
+    # scalars) even at world = 1, to see what that path costs per trip without a second GPU
+    force_dist = os.environ.get("ITS_BENCH_FORCE_DIST", "0") == "1"
+    if world == 1 and not force_dist:
         rp, col, val = matgen.laplace3d_7pt(N)
         n = len(rp) - 1
         nnz = len(col)
@@ -181,12 +184,12 @@ def main():
                     # what the kernel is asked to move: the 7-pt matrix has 7 distinct col-row offsets, so the
                     # exact kernel streams a 1-byte offset index instead of the 4-byte column (lossless)
                     "streamed_bytes": spmv_bytes(n, nnz) - (3 * nnz if (fmt == capi.FMT_CSR_EXACT and os.environ.get("ITS_SPMV_IDX", "1") != "0") else 0)}
-            for nm, f in ((("exact", capi.FMT_CSR_EXACT), ("vector", capi.FMT_CSR_VECTOR)) if world == 1 else ()):
+            for nm, f in ((("exact", capi.FMT_CSR_EXACT), ("vector", capi.FMT_CSR_VECTOR)) if (world == 1 and not force_dist) else ()):
                 h.spmv_timed(xd, yd, f, reps=3)
                 ms = h.spmv_timed(xd, yd, f, reps=a.spmv_reps)
                 spmv_all[nm] = {"ms": ms, "GB/s": spmv_bytes(n, nnz) / (ms * 1e-3) / 1e9}
         opt_in = None
-        if world == 1 and fmt == capi.FMT_CSR_EXACT:
+        if world == 1 and not force_dist and fmt == capi.FMT_CSR_EXACT:
             # opt-in (never `value`): the 7-pt matrix also has only 2 distinct values, so val can stream as a
             # 1-byte dictionary index too (lossless, bit-identical results; its_set_option "spmv_valdict")
             h.set_option("spmv_valdict", 1)
@@ -197,7 +200,7 @@ def main():
                                        "streamed_bytes": spmv_bytes(n, nnz) - 10 * nnz}}
             h.set_option("spmv_valdict", 0)
         cpu = None
-        if not a.no_cpu and world == 1:
+        if not a.no_cpu and world == 1 and not force_dist:
             cpu = cpu_baseline(rp, col, val, n)
         out = {
             "metric": "cg_iters_per_sec", "value": its_per_s * world, "unit": f"it/s ({N}^3-slab iterations)",

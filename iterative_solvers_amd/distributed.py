@@ -120,7 +120,19 @@ def init_comm(handle: capi.Handle, rank: int, world: int, rdzv) -> None:
         handle.check(L.its_comm_unique_id(C.byref(ids, 128)), "its_comm_unique_id")
     blob = rdzv.broadcast(ids.raw if rank == 0 else None)
     buf = C.create_string_buffer(blob, 256)
-    handle.check(L.its_comm_init(handle.h, rank, world, buf), "its_comm_init")
+    # RCCL 2.27 prints a version banner on STDOUT at communicator creation; callers such as bench.py own
+    # stdout (one JSON line), so file descriptor 1 points at stderr for the duration of the call
+    import os
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        rc = L.its_comm_init(handle.h, rank, world, buf)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+    handle.check(rc, "its_comm_init")
 
 
 _XCB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
