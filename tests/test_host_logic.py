@@ -144,3 +144,42 @@ def test_multicolor_order_is_valid(name):
         lev[i] = lev[c].max() + 1 if len(c) else 0
     assert lev.max() + 1 <= nc
     assert nc <= {"lap2d_16": 2, "lap3d_8": 2, "cd27_6": 8}.get(name, 64)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under iterative_solvers_amd/ (Python, C++, HIP, make files) and
+    neither C ABI header may import, include, link or execute it; only tests/, __graft_entry__.smoke() and
+    bench.py's cpu_baseline leg do."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"oracle_py|its_oracle|libits_oracle|orc_[a-z_]+\(|/oracle/|oracle\.|import oracle|from oracle")
+    bad = []
+    for base in ("iterative_solvers_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(root, base)):
+            for f in files:
+                if not f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".mk")) and f != "Makefile":
+                    continue
+                text = open(os.path.join(dp, f), errors="replace").read()
+                for m in pat.finditer(text):
+                    line = text[:m.start()].count("\n") + 1
+                    bad.append("%s:%d %s" % (os.path.relpath(os.path.join(dp, f), root), line, m.group(0)))
+    assert not bad, bad
+
+
+def test_library_refuses_to_run_without_a_gpu():
+    """No CPU fallback: without a HIP device its_create fails (the Python mirror raises)."""
+    import ctypes as C
+    from iterative_solvers_amd import capi
+    L = capi.lib()
+    h = C.c_void_p()
+    rc = L.its_create(C.byref(h), 0)
+    try:
+        import subprocess
+        has_gpu = subprocess.run(["/opt/rocm/bin/rocminfo"], capture_output=True, text=True).stdout.count("gfx9") > 0
+    except Exception:  # noqa: BLE001
+        has_gpu = False
+    if not has_gpu:
+        assert rc != 0 and not h.value
+    elif rc == 0:
+        L.its_destroy(h)
