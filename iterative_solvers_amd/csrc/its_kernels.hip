@@ -547,15 +547,6 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         }
         if (pend_row >= 0) a.y[pend_row] = pend_val;
     }
-#undef S4_DESC
-#undef S4_ISSUE
-#undef S4_DECODE
-#undef S4_VDEC0
-#undef S4_VDEC1
-#undef S4_COMMIT
-#undef S4_BATCH_LOAD
-#undef S4_BATCH_FMA
-#undef S4_BODY
     if (DOT || EPI == EPI_RESIDUAL) {
         const double bs = block_sum(lane_sum, s_red);
         if (t == 0 && a.part_sum) {
@@ -577,6 +568,179 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         }
     }
 }
+
+
+// --------------------------------------------------------------------------------------
+// v5 of the stream kernel (rows of at most 8 entries): a THREE-stage software pipeline.
+// One trip s of a workgroup
+//   1. commits row block s+1 (register set issued two trips ago) to LDS, barrier,
+//   2. reads row block s+1 out of LDS and ISSUES its x gathers (into the gather set of that parity),
+//   3. issues the col/val/row_ptr loads of row block s+3,
+//   4. runs the multiply-add chain of row block s, whose gathers went out ONE TRIP AGO, and parks the result
+//      (stored at step 2 of the next trip).
+// In v4 every trip waits for its own gathers (an L2 or HBM round trip with nothing else of that workgroup in
+// flight); here the round trip is hidden behind the next trip's LDS work and load issue, so a trip costs its
+// instruction issue, not a memory latency.  Same arithmetic and order as v4: bit-exact.
+// --------------------------------------------------------------------------------------
+struct GatherRegs { int c[8]; double v[8], x[8]; int j, j1, row, nr; double e0, e1, e2; };
+
+template <int EPI, bool DOT, int CMP>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_stream5_kernel(
+    int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
+    const int *__restrict__ col, const double *__restrict__ val, int n_rows,
+    const unsigned char *__restrict__ cidx, const int *__restrict__ off_dict,
+    const unsigned char *__restrict__ vidx, const double *__restrict__ val_dict, SpmvArgs a)
+{
+    constexpr bool IDX = CMP >= 1, VD = CMP == 2;
+    __shared__ double s_vdict[VD ? 256 : 1];
+    __shared__ __attribute__((aligned(16))) double s_val[2][S2_CAP];
+    __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];    // IDX: col - row, decoded at commit
+    __shared__ int s_rp[2][ITS_BLOCK + 4];
+    __shared__ int s_dict[IDX ? 256 : 1];
+    __shared__ double s_red[4];
+
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    if (IDX) {
+        s_dict[t] = off_dict[t];
+        if (VD) s_vdict[t] = val_dict[t];
+        __syncthreads();
+    }
+    int rb0, rb1, rstep;
+    if (a.map_mode == 0) {
+        const int slot = xcd_slot(blockIdx.x, G);
+        rb0 = (int)(((int64_t)slot * nb) / G);
+        rb1 = (int)(((int64_t)(slot + 1) * nb) / G);
+        rstep = 1;
+    } else {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        const int X0 = (int)(((int64_t)xcd * nb) / 8), X1 = (int)(((int64_t)(xcd + 1) * nb) / 8);
+        rb0 = X0 + jx; rb1 = X1; rstep = G >> 3;
+    }
+    const int niter = rb0 < rb1 ? (rb1 - rb0 + rstep - 1) / rstep : 0;
+
+    double lane_sum = 0.0, lane_max = 0.0;
+    double pend_val = 0.0;
+    int pend_row = -1;
+
+    // LDS reads of row block d (committed to `buf`) and its gathers + epilogue loads into gather set Gs
+#define S5_LOADGATHER(Gs, d, buf)                                                         \
+    do {                                                                                  \
+        Gs.nr = (d).y & 0xffff; Gs.row = (d).x + t;                                       \
+        Gs.j = 0; Gs.j1 = 0; Gs.e0 = 0.0; Gs.e1 = 0.0; Gs.e2 = 0.0;                       \
+        if (t < Gs.nr) {                                                                  \
+            const int base_ = (d).z & ~3;                                                 \
+            Gs.j = s_rp[buf][t] - base_; Gs.j1 = s_rp[buf][t + 1] - base_;                \
+            if (EPI == EPI_STORE && DOT) Gs.e0 = a.dotv[Gs.row];                          \
+            if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS) Gs.e0 = a.b[Gs.row]; \
+            if (EPI == EPI_JACOBI_SHIPPED) { Gs.e0 = a.D[Gs.row]; Gs.e1 = a.x[Gs.row]; Gs.e2 = a.b[Gs.row]; } \
+        }                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                   \
+            const bool ok_ = Gs.j + u < Gs.j1;                                            \
+            const int jj_ = ok_ ? Gs.j + u : 0;                                           \
+            const int cc_ = s_col[buf][jj_];                                              \
+            Gs.c[u] = ok_ ? (IDX ? Gs.row + cc_ : cc_) : 0; Gs.v[u] = s_val[buf][jj_];    \
+        }                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) Gs.x[u] = a.x[Gs.c[u]];             \
+    } while (0)
+    // the in-order chain of the row block whose gathers sit in Gs, its epilogue, result parked
+#define S5_FINISH(Gs)                                                                     \
+    do {                                                                                  \
+        double acc = 0.0, diag = 0.0;                                                     \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                   \
+            if (Gs.j + u < Gs.j1) {                                                       \
+                if (EPI == EPI_JACOBI_REF && Gs.c[u] == Gs.row) diag = Gs.v[u];           \
+                else acc = fma(Gs.v[u], Gs.x[u], acc);                                    \
+            }                                                                             \
+        }                                                                                 \
+        if (t < Gs.nr) {                                                                  \
+            double outv;                                                                  \
+            if (EPI == EPI_STORE) {                                                       \
+                outv = acc;                                                               \
+                if (DOT) lane_sum = fma(acc, Gs.e0, lane_sum);                            \
+            } else if (EPI == EPI_RESIDUAL) {                                             \
+                outv = Gs.e0 - acc;                                                       \
+                lane_sum = fma(outv, outv, lane_sum);                                     \
+                lane_max = fmax(lane_max, fabs(outv));                                    \
+            } else if (EPI == EPI_JACOBI_SHIPPED) {                                       \
+                const double adj = fma(-Gs.e0, acc, Gs.e1);                               \
+                outv = (Gs.e2 - adj) / Gs.e0;                                             \
+            } else if (EPI == EPI_JACOBI_REF) {                                           \
+                outv = (Gs.e0 - acc) / diag;                                              \
+            } else {                                                                      \
+                outv = fma(-1.0, acc, Gs.e0);                                             \
+            }                                                                             \
+            if (a.y) { pend_val = outv; pend_row = Gs.row; }                              \
+        }                                                                                 \
+    } while (0)
+    // one trip: R = register set of row block it+1, GN = its gather set, GO = gather set of row block it
+#define S5_STEP(R, GN, GO, buf)                                                           \
+    {                                                                                     \
+        const int4 dD = S4_DESC(it + 3);                                                  \
+        S4_COMMIT(R, dB, buf);                                                            \
+        __syncthreads();                                                                  \
+        if (pend_row >= 0) { a.y[pend_row] = pend_val; pend_row = -1; }                   \
+        S5_LOADGATHER(GN, dB, buf);                                                       \
+        S4_ISSUE(R, dD);                                                                  \
+        __builtin_amdgcn_sched_barrier(0);   /* the chain below must not move above the loads just issued */ \
+        S5_FINISH(GO);                                                                    \
+        dB = dC; dC = dD;                                                                 \
+        ++it;                                                                             \
+    }
+
+    if (niter > 0) {
+        StageRegs P, Q;
+        GatherRegs GA, GB;
+        const int4 dA = S4_DESC(0);
+        int4 dB = S4_DESC(1), dC = S4_DESC(2);
+        int it = 0;
+        S4_ISSUE(P, dA);
+        S4_ISSUE(Q, dB);
+        S4_COMMIT(P, dA, 0);
+        __syncthreads();
+        S5_LOADGATHER(GA, dA, 0);
+        S4_ISSUE(P, dC);
+        // trips come in pairs (block it+1 odd -> set Q, LDS buffer 1, gather set B; then even -> P, 0, A)
+        const int niter2 = (niter + 1) & ~1;
+        while (it < niter2) {
+            S5_STEP(Q, GB, GA, 1)
+            S5_STEP(P, GA, GB, 0)
+        }
+        if (pend_row >= 0) a.y[pend_row] = pend_val;
+    }
+#undef S5_LOADGATHER
+#undef S5_FINISH
+#undef S5_STEP
+    if (DOT || EPI == EPI_RESIDUAL) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) {
+            if (a.part_accum) a.part_sum[blockIdx.x] += bs;
+            else {
+                a.part_sum[blockIdx.x] = bs;
+                for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
+            }
+        }
+        if (EPI == EPI_RESIDUAL && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) {
+                if (a.part_accum) a.part_max[blockIdx.x] = fmax(a.part_max[blockIdx.x], bm);
+                else {
+                    a.part_max[blockIdx.x] = bm;
+                    for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_max[z] = 0.0;
+                }
+            }
+        }
+    }
+}
+#undef S4_DESC
+#undef S4_ISSUE
+#undef S4_DECODE
+#undef S4_VDEC0
+#undef S4_VDEC1
+#undef S4_COMMIT
+#undef S4_BATCH_LOAD
+#undef S4_BATCH_FMA
+#undef S4_BODY
 
 // --------------------------------------------------------------------------------------
 // Exact SpMV for IRREGULAR row lengths (power-law matrices): gather and arithmetic are split.
@@ -761,7 +925,7 @@ static int env_int(const char *name, int dflt)
 // launch tunables of the exact SpMV (its_set_option "spmv_grid" / "spmv_map" / "spmv_nt")
 // defaults measured on MI355X, 256^3 7-pt: v4 with 2 workgroups per CU (0.369 ms) vs v2 with 4 (0.376 ms)
 static int g_spmv_variant = env_int("ITS_SPMV_VARIANT", 4);
-static int g_spmv_grid = env_int("ITS_SPMV_GRID", g_spmv_variant == 4 ? 512 : 1024);
+static int g_spmv_grid = env_int("ITS_SPMV_GRID", g_spmv_variant >= 4 ? 512 : 1024);
 static int g_spmv_map = env_int("ITS_SPMV_MAP", 1);
 static int g_spmv_idx = env_int("ITS_SPMV_IDX", 1);             // 0 = never use the 1-byte column-offset stream
 static int g_spmv_valdict = env_int("ITS_SPMV_VALDICT", 0);     // opt-in: 1-byte value-dictionary stream
@@ -774,7 +938,7 @@ int spmv_tune(const char *name, int value)
 {
     if (!strcmp(name, "spmv_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_grid = value; return 0; }
     if (!strcmp(name, "spmv_map")) { if (value < 0 || value > 1) return -1; g_spmv_map = value; return 0; }
-    if (!strcmp(name, "spmv_variant")) { if (value != 1 && value != 2 && value != 4) return -1; g_spmv_variant = value; return 0; }
+    if (!strcmp(name, "spmv_variant")) { if (value != 1 && value != 2 && value != 4 && value != 5) return -1; g_spmv_variant = value; return 0; }
     if (!strcmp(name, "spmv_idx")) { if (value < 0 || value > 1) return -1; g_spmv_idx = value; return 0; }
     if (!strcmp(name, "spmv_valdict")) { if (value < 0 || value > 1) return -1; g_spmv_valdict = value; return 0; }
     if (!strcmp(name, "spmv_irr")) { if (value < 0 || value > 1) return -1; g_spmv_irr = value; return 0; }
@@ -788,7 +952,7 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
                             int accumulate, hipStream_t s)
 {
     int g2v = g_spmv_grid;
-    const int g2v_long = g_spmv_variant == 4 ? 1024 : g2v;   // v2's own best grid (4 workgroups per CU)
+    const int g2v_long = g_spmv_variant >= 4 ? 1024 : g2v;   // v2's own best grid (4 workgroups per CU)
     const int mm = g_spmv_map;
     if (g2v < 8 || g2v > ITS_NPART || (g2v & 7)) g2v = 1024;
     dim3 g2(g2v), b(ITS_BLOCK);
@@ -833,6 +997,26 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
     } while (0)
     // v4 keeps one batch of 8 gathers per row in flight; rows of 9..32 entries (27-pt) run faster in v2,
     // whose per-lane batch loop does not wait for the longest row of the block (0.169 vs 0.213 ms, 27-pt 128^3)
+    // v5 (gathers one trip ahead of their multiply-adds) wins only once the streams are tiny: it is used for the
+    // opt-in value-dictionary mode (0.183 vs 0.205 ms) and on request (variant 5); otherwise v4 (0.315 vs 0.320 ms)
+    const int cmp = (A.n_off > 0 && g_spmv_idx) ? ((A.n_vals > 0 && g_spmv_valdict) ? 2 : 1) : 0;
+    if (A.max_row_len <= 8 && (g_spmv_variant == 5 || (g_spmv_variant == 4 && cmp == 2))) {
+        if (cmp == 2) g2 = dim3(g_spmv_vd_grid);
+#define ITS_LAUNCH5C(E, D, C)                                                                                 \
+    hipLaunchKernelGGL((spmv_stream5_kernel<E, D, C>), g2, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val,    \
+                       A.n_rows, A.cidx, A.off_dict, A.vidx, A.val_dict, a)
+#define ITS_LAUNCH5(E, D) do { if (cmp == 2) ITS_LAUNCH5C(E, D, 2); else if (cmp == 1) ITS_LAUNCH5C(E, D, 1); else ITS_LAUNCH5C(E, D, 0); } while (0)
+        switch (epi) {
+        case EPI_STORE: if (a.dotv) ITS_LAUNCH5(EPI_STORE, true); else ITS_LAUNCH5(EPI_STORE, false); break;
+        case EPI_RESIDUAL: ITS_LAUNCH5(EPI_RESIDUAL, false); break;
+        case EPI_JACOBI_SHIPPED: ITS_LAUNCH5(EPI_JACOBI_SHIPPED, false); break;
+        case EPI_JACOBI_REF: ITS_LAUNCH5(EPI_JACOBI_REF, false); break;
+        case EPI_GS_RHS: ITS_LAUNCH5(EPI_GS_RHS, false); break;
+        }
+#undef ITS_LAUNCH5
+#undef ITS_LAUNCH5C
+        return;
+    }
     if (g_spmv_variant == 4 && A.max_row_len <= 8) {
         switch (epi) {
         case EPI_STORE: if (a.dotv) ITS_LAUNCH4(EPI_STORE, true); else ITS_LAUNCH4(EPI_STORE, false); break;

@@ -140,7 +140,16 @@ __global__ __launch_bounds__(BLK) void k_stream(int nb, const int4 *__restrict__
                 int c[8]; double v[8], xv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const int jj = (j + u < j1) ? j + u : j; c[u] = s_col[cur][jj]; v[u] = s_val[cur][jj]; }
-                if (STAGE >= 3 && STAGE != 6) {
+                if (STAGE == 11 || STAGE == 12 || STAGE == 13) {
+                    // probe: how much do gathers into cache lines that are still in flight cost?  11 drops the
+                    // x-1 / x+1 gathers (slots 2 and 4 of an interior 7-pt row), 12 also the padding slot 7,
+                    // 13 keeps only the two far (z-1, z+1) gathers.  Timing only (wrong results).
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool drop = STAGE == 13 ? (u != 0 && u != 6) : ((u == 2 || u == 4) || (STAGE == 12 && u == 7));
+                        xv[u] = drop ? (double)c[u] : x[c[u]];
+                    }
+                } else if (STAGE >= 3 && STAGE != 6) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
                 } else {
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(BLK) void k_stream(int nb, const int4 *__restrict__
             if (STAGE == 5) { pend = acc; pend_row = row; }
             else if (STAGE == 8) const_cast<double *>(x)[row] = acc * 0.05;
             else if (STAGE == 9) y[row & 0xffff] = acc;
-            else if (STAGE >= 4) y[row] = acc; else sink += acc;
+            else if (STAGE >= 4 && STAGE < 11) y[row] = acc; else sink += acc;
         }
         cur ^= 1; d = dn; dn = dnn;
     }
@@ -352,7 +361,7 @@ int main(int argc, char **argv)
     { float ms = time_ms(s, reps, [&] { CK(hipMemsetAsync(d_y, 0, n * 8, s)); }); printf("memset %lld MB: %.4f ms (%.0f GB/s)\n", (long long)(n * 8 >> 20), ms, n * 8.0 / ms / 1e6); }
 #define RUN(ST) do { float ms = time_ms(s, reps, [&] { hipLaunchKernelGGL((k_stream<ST, CAP>), dim3(1024), dim3(BLK), 0, s, nb, d_desc, d_rp, d_col, d_val, d_x, d_y, d_out); }); \
         printf("k_stream stage %d: %.4f ms (stream %.0f GB/s, full %.0f GB/s)\n", ST, ms, stream_bytes / ms / 1e6, full_bytes / ms / 1e6); } while (0)
-    RUN(3); RUN(4);
+    RUN(2); RUN(3); RUN(11); RUN(12); RUN(13); RUN(4);
 #define RUNB(K, GRID) do { float ms = time_ms(s, reps, [&] { hipLaunchKernelGGL((k_stream_burst<K>), dim3(GRID), dim3(BLK), 0, s, nb, d_desc, d_rp, d_col, d_val, d_x, d_y, d_out); }); \
         printf("k_stream_burst K=%d grid %d: %.4f ms (full %.0f GB/s)\n", K, GRID, ms, full_bytes / ms / 1e6); } while (0)
     RUNB(1, 1024); RUNB(2, 1024); RUNB(4, 768); RUNB(4, 1024); RUNB(8, 768); RUNB(16, 512); RUNB(8, 512);
