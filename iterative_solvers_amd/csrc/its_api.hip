@@ -14,7 +14,7 @@
 
 static void free_csr(CsrDev &A)
 {
-    dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_row); dfree(A.blk_desc);
+    dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc);
     dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict); dfree(A.vidx); dfree(A.val_dict);
     A = CsrDev();
 }
@@ -248,8 +248,6 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     std::vector<int> blk;
     build_stream_plan(n_rows, row_ptr, blk);
     A.n_blocks = (int)blk.size() - 1;
-    if (dalloc(h, &A.blk_row, blk.size())) return ITS_EHIP;
-    HIPCHK(h, hipMemcpy(A.blk_row, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
     std::vector<int4> desc(std::max(A.n_blocks, 1));
     for (int i = 0; i < A.n_blocks; ++i) {
         // .y = rows | (longest row of the block, capped) << 16: the kernel's batch count

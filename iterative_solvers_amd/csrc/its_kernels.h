@@ -10,10 +10,10 @@ namespace its {
 // ---------------------------------------------------------------------------------------
 // CSR "stream" plan: rows are cut into row blocks of at most ITS_BLOCK rows and at most
 // SPMV_NNZ_MAX nonzeros (a single longer row forms a block of its own and is walked in
-// several LDS chunks).  blk_row[nb+1] holds the first row of each block.
+// several LDS chunks).  blk_desc[nb] = {first row, rows | longest row << 16, first nnz, end nnz}.
 // ---------------------------------------------------------------------------------------
-constexpr int SPMV_NNZ_MAX = 1536;
-constexpr int IRR_ROW_LEN = 32;           // longest row above which the exact SpMV splits gather and arithmetic      // (1536+8)*(8+4) B + row ptrs ≈ 19.6 KB LDS per buffer
+constexpr int SPMV_NNZ_MAX = 1536;        // (1536+8)*(8+4) B + row ptrs ≈ 19.6 KB LDS per buffer
+constexpr int IRR_ROW_LEN = 32;           // longest row above which the exact SpMV splits gather and arithmetic
 // col/val are allocated with this many zero elements after nnz: the stream kernel's prefetch
 // loads are unconditional (2 slices x 1024 entries past an aligned block start)
 constexpr int CSR_PAD = 2048 + 16;
@@ -43,7 +43,6 @@ struct CsrDev {
     int n_vals = 0;                           // 0 = not eligible
     // stream plan
     int n_blocks = 0;
-    int *blk_row = nullptr;
     int4 *blk_desc = nullptr;                 // {first row, rows, first nnz, end nnz} per row block
     // vector-CSR plan
     int lanes_per_row = 0;

@@ -1,6 +1,6 @@
 // its_kernels.hip — hand-written gfx950 kernels for the iterative-solver hot path.
-// All kernels: 256-thread workgroups (4 wavefronts of 64), grid = ITS_NPART workgroups
-// (8 per CU on 256 CUs) walking their share of the work; HBM-bandwidth bound, no MFMA.
+// All kernels: 256-thread workgroups (4 wavefronts of 64), persistent grids walking their share of the
+// work (2-5 workgroups per CU for the SpMV pipelines, ITS_NPART for the vector kernels); HBM-bound, no MFMA.
 #include "its_kernels.h"
 #include <cstdlib>
 #include <cstring>
@@ -8,101 +8,12 @@
 namespace its {
 
 // ======================================================================================
-// SpMV, CSR "stream": bit-exact restatement of spmv_crs_cpu (kernels.hpp:380-409).
-//   * a workgroup owns a contiguous run of row blocks (XCD-aware slot, see xcd_slot);
-//   * per row block the col/val segment is streamed with 16-byte-per-lane coalesced loads
-//     into LDS, then ONE LANE PER ROW walks its row out of LDS in CRS order with one fused
-//     multiply-add per entry starting from 0.0 — the reference's arithmetic exactly;
-//   * x gathers go to L1/L2 (for banded matrices consecutive lanes hit consecutive x).
+// SpMV, scalar CSR, bit-exact: the "stream" kernels.  The col/val slice of a row block (<= 256 rows,
+// <= SPMV_NNZ_MAX entries, plan built at upload) is copied from HBM into LDS with 16-byte loads by all 256
+// lanes, then lane i walks row i from LDS in CRS order with fused multiply-adds from 0.0 — the operations
+// and the order of spmv_crs_cpu (kernels.hpp:380-409).  Three pipelines share that idea: v2 (rows of 9..32
+// entries), v4 / v5 (rows of at most 8) and the two-phase kernel for irregular rows.
 // ======================================================================================
-template <int EPI, bool DOT>
-__global__ __launch_bounds__(ITS_BLOCK) void spmv_stream_kernel(
-    int nb, const int *__restrict__ blk_row, const int *__restrict__ rp,
-    const int *__restrict__ col, const double *__restrict__ val, SpmvArgs a)
-{
-    __shared__ __attribute__((aligned(16))) double s_val[SPMV_NNZ_MAX + 8];
-    __shared__ __attribute__((aligned(16))) int s_col[SPMV_NNZ_MAX + 8];
-    __shared__ int s_rp[ITS_BLOCK + 1];
-    __shared__ double s_red[4];
-
-    const int t = threadIdx.x;
-    const int G = gridDim.x;
-    const int slot = xcd_slot(blockIdx.x, G);
-    const int rb0 = (int)(((int64_t)slot * nb) / G);
-    const int rb1 = (int)(((int64_t)(slot + 1) * nb) / G);
-
-    double lane_sum = 0.0, lane_max = 0.0;
-
-    for (int rb = rb0; rb < rb1; ++rb) {
-        const int rs = blk_row[rb];
-        const int nr = blk_row[rb + 1] - rs;
-        for (int i = t; i <= nr; i += ITS_BLOCK) s_rp[i] = rp[rs + i];
-        __syncthreads();
-        const int a0 = s_rp[0], a1 = s_rp[nr];
-        int my0 = 0, my1 = 0;
-        if (t < nr) { my0 = s_rp[t]; my1 = s_rp[t + 1]; }
-        double acc = 0.0;
-        double diag = 0.0;
-        const int row = rs + t;
-        for (int c0 = a0; c0 < a1; c0 += SPMV_NNZ_MAX) {
-            const int c1 = min(a1, c0 + SPMV_NNZ_MAX);
-            const int base = c0 & ~3;   // 16-byte aligned start for the int4 / double2 streams
-            for (int i = base + 4 * t; i < c1; i += 4 * ITS_BLOCK) {
-                const int4 cc = *reinterpret_cast<const int4 *>(col + i);
-                const double2 v0 = *reinterpret_cast<const double2 *>(val + i);
-                const double2 v1 = *reinterpret_cast<const double2 *>(val + i + 2);
-                const int o = i - base;
-                *reinterpret_cast<int4 *>(s_col + o) = cc;
-                *reinterpret_cast<double2 *>(s_val + o) = v0;
-                *reinterpret_cast<double2 *>(s_val + o + 2) = v1;
-            }
-            __syncthreads();
-            if (t < nr) {
-                const int j0 = max(my0, c0) - base, j1 = min(my1, c1) - base;
-                for (int j = j0; j < j1; ++j) {
-                    const int c = s_col[j];
-                    const double v = s_val[j];
-                    if (EPI == EPI_JACOBI_REF) {
-                        if (c == row) diag = v;
-                        else acc = fma(v, a.x[c], acc);
-                    } else {
-                        acc = fma(v, a.x[c], acc);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (a0 == a1) __syncthreads();   // keep s_rp stable until every lane has read it
-        if (t < nr) {
-            if (EPI == EPI_STORE) {
-                a.y[row] = acc;
-                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
-            } else if (EPI == EPI_RESIDUAL) {
-                const double r = a.b[row] - acc;
-                if (a.y) a.y[row] = r;                       // y == nullptr: only the norm is wanted
-                lane_sum = fma(r, r, lane_sum);
-                lane_max = fmax(lane_max, fabs(r));
-            } else if (EPI == EPI_JACOBI_SHIPPED) {
-                const double d = a.D[row];
-                const double adj = fma(-d, acc, a.x[row]);
-                a.y[row] = (a.b[row] - adj) / d;
-            } else if (EPI == EPI_JACOBI_REF) {
-                a.y[row] = (a.b[row] - acc) / diag;
-            } else if (EPI == EPI_GS_RHS) {
-                a.y[row] = fma(-1.0, acc, a.b[row]);
-            }
-        }
-    }
-    if (DOT || EPI == EPI_RESIDUAL) {
-        const double bs = block_sum(lane_sum, s_red);
-        if (t == 0 && a.part_sum) a.part_sum[blockIdx.x] = bs;
-        if (EPI == EPI_RESIDUAL && a.part_max) {
-            const double bm = block_max(lane_max, s_red);
-            if (t == 0) a.part_max[blockIdx.x] = bm;
-        }
-    }
-}
-
 // --------------------------------------------------------------------------------------
 // v2 of the stream kernel: software-pipelined, one barrier per row block.
 //   * while one lane per row walks row block rb out of LDS buffer `cur`, the col/val/row_ptr
@@ -938,7 +849,7 @@ int spmv_tune(const char *name, int value)
 {
     if (!strcmp(name, "spmv_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_grid = value; return 0; }
     if (!strcmp(name, "spmv_map")) { if (value < 0 || value > 1) return -1; g_spmv_map = value; return 0; }
-    if (!strcmp(name, "spmv_variant")) { if (value != 1 && value != 2 && value != 4 && value != 5) return -1; g_spmv_variant = value; return 0; }
+    if (!strcmp(name, "spmv_variant")) { if (value != 2 && value != 4 && value != 5) return -1; g_spmv_variant = value; return 0; }
     if (!strcmp(name, "spmv_idx")) { if (value < 0 || value > 1) return -1; g_spmv_idx = value; return 0; }
     if (!strcmp(name, "spmv_valdict")) { if (value < 0 || value > 1) return -1; g_spmv_valdict = value; return 0; }
     if (!strcmp(name, "spmv_irr")) { if (value < 0 || value > 1) return -1; g_spmv_irr = value; return 0; }
@@ -969,7 +880,7 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
                                A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
     } while (0)
     // irregular rows: the two-phase kernel (5 workgroups per CU by its LDS footprint)
-    if (A.max_row_len > g_spmv_irr_len && g_spmv_variant != 1 && g_spmv_irr) {
+    if (A.max_row_len > g_spmv_irr_len && g_spmv_irr) {
         dim3 gi(g_spmv_irr_grid);
 #define ITS_LAUNCHI(E, D) \
     hipLaunchKernelGGL((spmv_irr_kernel<E, D>), gi, b, 0, s, n_desc, desc, A.row_ptr, A.col, A.val, A.n_rows, a)
@@ -1040,21 +951,7 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
 
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
 {
-    const int variant = g_spmv_variant;
-    dim3 b(ITS_BLOCK);
-    if (variant != 1) { launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s); return; }
-    const SpmvArgs &a = a_in;
-    dim3 g(ITS_NPART);
-#define ITS_LAUNCH(E, D) \
-    hipLaunchKernelGGL((spmv_stream_kernel<E, D>), g, b, 0, s, A.n_blocks, A.blk_row, A.row_ptr, A.col, A.val, a)
-    switch (epi) {
-    case EPI_STORE: if (a.dotv) ITS_LAUNCH(EPI_STORE, true); else ITS_LAUNCH(EPI_STORE, false); break;
-    case EPI_RESIDUAL: ITS_LAUNCH(EPI_RESIDUAL, false); break;
-    case EPI_JACOBI_SHIPPED: ITS_LAUNCH(EPI_JACOBI_SHIPPED, false); break;
-    case EPI_JACOBI_REF: ITS_LAUNCH(EPI_JACOBI_REF, false); break;
-    case EPI_GS_RHS: ITS_LAUNCH(EPI_GS_RHS, false); break;
-    }
-#undef ITS_LAUNCH
+    launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s);
 }
 
 // ======================================================================================
