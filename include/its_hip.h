@@ -78,7 +78,7 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *   "spmv_valdict" 1 = also stream values as 1-byte dictionary indices (<= 256 distinct fp64 values);
  *                  default 0
  *   "spmv_irr"     1 (default) = two-phase kernel when the longest row exceeds 32 entries
- *   "spmv_variant" 4 (default) | 2 | 1, "spmv_grid", "spmv_irr_grid", "spmv_map" 0|1, "spmv_nt" 0..3:
+ *   "spmv_variant" 4 (default) | 5 | 2, "spmv_grid", "spmv_irr_grid", "spmv_irr_len", "spmv_map" 0|1:
  *                  tuning knobs kept for A/B measurements (tools/spmv_ab.py) */
 int its_set_option(its_handle *h, const char *name, int value);
 

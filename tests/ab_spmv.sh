@@ -1,5 +1,5 @@
 #!/bin/bash
-for cfg in "2 1024 1" "2 1024 0" "2 768 1" "1 2048 0"; do
+for cfg in "4 512 1" "4 768 1" "5 512 1" "2 1024 1"; do
   set -- $cfg
   ITS_SPMV_VARIANT=$1 ITS_SPMV_GRID=$2 ITS_SPMV_MAP=$3 timeout -k 10 120 python bench.py --steps 50 --warmup 5 --no-cpu 2>/dev/null | python -c "
 import json,sys
