@@ -123,8 +123,9 @@ int its_synchronize(its_handle *h);
 /* ---- introspection for bench.py ----------------------------------------------------- */
 /* average duration (ms) of the last its_spmv_timed / its_iterate_n region, measured with HIP
  * events on the handle's own stream */
-/* with_dot != 0 launches the variant the CG loop uses (y = A x fused with the partial sums
- * of y.x, methods/cg.hpp:128,160) so its duration matches the in-loop kernel. */
+/* with_dot == 1 launches the variant the CG loop uses (y = A x fused with the partial sums
+ * of y.x, methods/cg.hpp:128,160) so its duration matches the in-loop kernel; 2 and 3 time the residual
+ * epilogue (r = x - A x, with x standing in for b) with r stored (2) and norm-only (3). */
 int its_spmv_timed(its_handle *h, int which, const double *x_dev, double *y_dev, int format,
                    int with_dot, int reps, float *avg_ms);
 int its_last_region_ms(its_handle *h, float *ms);

@@ -866,9 +866,12 @@ extern "C" int its_spmv_timed(its_handle *h, int which, const double *x_dev, dou
     if (!h->have[which]) FAIL(h, ITS_ESTATE, "matrix not uploaded");
     HIPCHK(h, hipSetDevice(h->device));
     SpmvArgs a; a.x = x_dev; a.y = y_dev;
-    if (with_dot) { a.dotv = x_dev; a.part_sum = h->part[3]; }
+    int epi = EPI_STORE;
+    if (with_dot == 1) { a.dotv = x_dev; a.part_sum = h->part[3]; }
+    // measurement forms of the residual epilogue (r = b - A x with its norm): 2 = r stored, 3 = norm only
+    if (with_dot == 2 || with_dot == 3) { epi = EPI_RESIDUAL; a.b = x_dev; a.part_sum = h->part[3]; if (with_dot == 3) a.y = nullptr; }
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < reps; ++i) { int rc = spmv_dispatch(h, h->mat[which], a, EPI_STORE, format); if (rc) return rc; }
+    for (int i = 0; i < reps; ++i) { int rc = spmv_dispatch(h, h->mat[which], a, epi, format); if (rc) return rc; }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     float ms = 0.f;

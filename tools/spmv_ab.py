@@ -33,4 +33,14 @@ for rnd in range(ROUNDS):
         h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=5)
         ms = h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=REPS)
         msd = h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=REPS, with_dot=True)
-        print("%-32s plain %.4f ms (%.0f GB/s)   with-dot %.4f ms (%.0f GB/s)" % (cfg, ms, by / ms / 1e6, msd, by / msd / 1e6), flush=True)
+        line = "%-32s plain %.4f ms (%.0f GB/s)   with-dot %.4f ms (%.0f GB/s)" % (cfg, ms, by / ms / 1e6, msd, by / msd / 1e6)
+        if os.environ.get("RES"):
+            # residual epilogue with and without storing r: what the y store costs inside the library kernel
+            L = h.L; import ctypes as C
+            out = C.c_float()
+            def timed(mode):
+                h.check(L.its_spmv_timed(h.h, capi.MAT_A, C.c_void_p(xd), C.c_void_p(yd), capi.FMT_CSR_EXACT, mode, 5, C.byref(out)), "t")
+                h.check(L.its_spmv_timed(h.h, capi.MAT_A, C.c_void_p(xd), C.c_void_p(yd), capi.FMT_CSR_EXACT, mode, REPS, C.byref(out)), "t")
+                return out.value
+            line += "   residual: stored %.4f  norm-only %.4f" % (timed(2), timed(3))
+        print(line, flush=True)

@@ -163,6 +163,9 @@ __global__ __launch_bounds__(BLK) void k_stream(int nb, const int4 *__restrict__
             if (STAGE == 5) { pend = acc; pend_row = row; }
             else if (STAGE == 8) const_cast<double *>(x)[row] = acc * 0.05;
             else if (STAGE == 9) y[row & 0xffff] = acc;
+            else if (STAGE == 14) { if ((it & 1) == 0) y[row] = acc; else sink += acc; }      // half the store instructions
+            else if (STAGE == 15) { if ((t & 1) == 0) y[row] = acc; else sink += acc; }       // same instructions and lines, half the bytes
+            else if (STAGE == 16) { if ((it & 3) == 0) y[row] = acc; else sink += acc; }      // a quarter of the store instructions
             else if (STAGE >= 4 && STAGE < 11) y[row] = acc; else sink += acc;
         }
         cur ^= 1; d = dn; dn = dnn;
@@ -362,7 +365,7 @@ int main(int argc, char **argv)
     { float ms = time_ms(s, reps, [&] { CK(hipMemsetAsync(d_y, 0, n * 8, s)); }); printf("memset %lld MB: %.4f ms (%.0f GB/s)\n", (long long)(n * 8 >> 20), ms, n * 8.0 / ms / 1e6); }
 #define RUN(ST) do { float ms = time_ms(s, reps, [&] { hipLaunchKernelGGL((k_stream<ST, CAP>), dim3(1024), dim3(BLK), 0, s, nb, d_desc, d_rp, d_col, d_val, d_x, d_y, d_out); }); \
         printf("k_stream stage %d: %.4f ms (stream %.0f GB/s, full %.0f GB/s)\n", ST, ms, stream_bytes / ms / 1e6, full_bytes / ms / 1e6); } while (0)
-    RUN(2); RUN(3); RUN(11); RUN(12); RUN(13); RUN(4);
+    RUN(3); RUN(4); RUN(14); RUN(15); RUN(16);
 #define RUNB(K, GRID) do { float ms = time_ms(s, reps, [&] { hipLaunchKernelGGL((k_stream_burst<K>), dim3(GRID), dim3(BLK), 0, s, nb, d_desc, d_rp, d_col, d_val, d_x, d_y, d_out); }); \
         printf("k_stream_burst K=%d grid %d: %.4f ms (full %.0f GB/s)\n", K, GRID, ms, full_bytes / ms / 1e6); } while (0)
     RUNB(1, 1024); RUNB(2, 1024); RUNB(4, 768); RUNB(4, 1024); RUNB(8, 768); RUNB(16, 512); RUNB(8, 512);
