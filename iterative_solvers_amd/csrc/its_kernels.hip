@@ -928,7 +928,9 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
 #undef ITS_LAUNCH5C
         return;
     }
-    if (g_spmv_variant == 4 && A.max_row_len <= 8) {
+    // measured (256^3 7-pt, offset stream): v4 wins inside the CG loop (0.511 vs 0.522 ms per trip), v2 wins for
+    // every other epilogue (plain 0.303 vs 0.316 ms, Jacobi trip 0.620 vs 0.672 ms, norm-only residual 0.245 vs 0.299)
+    if (g_spmv_variant == 4 && A.max_row_len <= 8 && epi == EPI_STORE && a.dotv) {
         switch (epi) {
         case EPI_STORE: if (a.dotv) ITS_LAUNCH4(EPI_STORE, true); else ITS_LAUNCH4(EPI_STORE, false); break;
         case EPI_RESIDUAL: ITS_LAUNCH4(EPI_RESIDUAL, false); break;
