@@ -687,14 +687,17 @@ extern "C" int its_iterate(its_handle *h, int iter_count, double *residual_norm)
         if (rc == ITS_OK) h->last_residual = *residual_norm;
         return rc;
     }
-    double *res = h->sc + SC_RES;
+    // the last kernel of the trip writes the recorded value straight into pinned host memory (GPU-visible on
+    // ROCm), so the trip ends with one stream sync and no copy; an all-reduced value stays on the device first
+    const bool direct = !its_dist_active(h) && getenv("ITS_READBACK_COPY") == nullptr;
+    double *res = direct ? h->pinned + 2000 : h->sc + SC_RES;
     if (h->solver == ITS_CG) rc = trip_cg(h, res);
     else if (h->solver == ITS_JACOBI) rc = trip_jacobi(h, res);
     else rc = trip_gs(h, res);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->pinned, res, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (!direct) HIPCHK(h, hipMemcpyAsync(h->pinned + 2000, res, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    *residual_norm = h->last_residual = h->pinned[0];
+    *residual_norm = h->last_residual = h->pinned[2000];
     return ITS_OK;
 }
 
