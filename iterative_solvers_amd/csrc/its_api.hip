@@ -260,6 +260,10 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     A.lanes_per_row = pick_lanes_per_row(n_rows, nnz);
     A.max_row_len = 0;
     for (int i = 0; i < n_rows; ++i) A.max_row_len = std::max(A.max_row_len, row_ptr[i + 1] - row_ptr[i]);
+    A.n_upper = 0;
+    if (which != ITS_MAT_L)                              // what trip_gs compares between A and crs_U
+        for (int i = 0; i < n_rows; ++i)
+            for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k) A.n_upper += col[k] > i;
     if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; }
     h->have[which] = true;
     if (which == ITS_MAT_A) { h->fmt = format; h->setup_done = false; h->residual_done = false; }
@@ -283,6 +287,12 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "gmres_givens: 0 (rotations) or 1 (reference dense products)");
         if (h->setup_done && h->solver == ITS_GMRES) FAIL(h, ITS_ESTATE, "set gmres_givens before its_solver_setup");
         h->gmres_givens = value;
+        return ITS_OK;
+    }
+    if (!strcmp(name, "fused_residual")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "fused_residual: 0 or 1");
+        h->fused_residual = value;
+        h->ahead = false;
         return ITS_OK;
     }
     {
@@ -363,7 +373,7 @@ extern "C" int its_upload_vectors(its_handle *h, const double *D, const double *
     HIPCHK(h, hipMemcpyAsync(h->b, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->x_a, x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));   // x_old
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->setup_done = false; h->residual_done = false;
+    h->setup_done = false; h->residual_done = false; h->ahead = false;
     return ITS_OK;
 }
 
@@ -493,6 +503,7 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
     HIPCHK(h, hipGetLastError());
     h->setup_done = true;
     h->last_residual = 0.0;
+    h->ahead = false;
     return ITS_OK;
 }
 
@@ -533,6 +544,24 @@ static int trip_jacobi(its_handle *h, double *res_out)
     // exchange_arrays both hold the same values, solver.hpp:796-798); x_b receives the new iterate.
     SpmvArgs a; a.y = h->x_b; a.b = h->b; a.D = h->D;
     int rc;
+    if (h->jacobi_mode != ITS_JACOBI_SHIPPED && h->fused_residual) {
+        // One pass over A per trip.  The pass that records ||b - A x_new|| walks the same rows of A that the
+        // next trip's sweep of x_new needs, so it produces that sweep too (second in-order chain, same bits as
+        // a launch of its own) into the spare vector; the next trip starts with its iterate already there.
+        if (!h->ahead) {
+            a.x = h->x_a;
+            if ((rc = solver_spmv(h, a, EPI_JACOBI_REF))) return rc;
+        }
+        SpmvArgs f; f.x = h->x_b; f.y = h->x; f.b = h->b; f.part_sum = h->part[0];
+        if ((rc = solver_spmv(h, f, EPI_JACOBI_FUSED))) return rc;
+        if ((rc = finish_scalar(h, h->part[0], res_out, FIN_SQRT))) return rc;
+        double *spare = h->x_a;
+        h->x_a = h->x_b;                                              // exchange_arrays: the new iterate
+        h->x_b = h->x;                                                // the iterate after it
+        h->x = spare;
+        h->ahead = true;
+        return ITS_OK;
+    }
     if (h->jacobi_mode == ITS_JACOBI_SHIPPED) {
         a.x = h->x_a;
         rc = solver_spmv(h, a, EPI_JACOBI_SHIPPED);
@@ -553,9 +582,24 @@ static int trip_jacobi(its_handle *h, double *res_out)
 static int trip_gs(its_handle *h, double *res_out)
 {
     SpmvArgs u; u.x = h->x; u.y = h->tmp; u.b = h->b;
-    int rc = spmv_dispatch(h, h->mat[ITS_MAT_U], u, EPI_GS_RHS, ITS_FMT_CSR_EXACT);   // gauss_seidel.hpp:144,177
-    if (rc) return rc;
+    int rc;
+    // crs_U is the strictly upper part of A (gauss_seidel.hpp:433-450 builds it so; the entry counts are
+    // compared): the residual pass over A then also yields b - U x_new for the next trip (EPI_GS_FUSED)
+    // (not for matrices on the irregular-row kernel: its one-lane-per-row walk out of LDS is issue-bound, and the
+    // per-entry column test of the second chain costs more there than the separate pass over U: 2.7 vs 2.3 ms on
+    // the power-law matrix in multicolour order)
+    const bool fused = h->fused_residual && h->mat[ITS_MAT_U].nnz == h->mat[ITS_MAT_A].n_upper &&
+                       h->mat[ITS_MAT_A].max_row_len <= IRR_ROW_LEN;
+    if (!(fused && h->ahead)) {
+        if ((rc = spmv_dispatch(h, h->mat[ITS_MAT_U], u, EPI_GS_RHS, ITS_FMT_CSR_EXACT))) return rc;   // gauss_seidel.hpp:144,177
+    }
     if ((rc = sweep(h, h->x, h->tmp))) return rc;                                      // :227
+    if (fused) {
+        SpmvArgs f; f.x = h->x; f.y = h->tmp; f.b = h->b; f.part_sum = h->part[0];
+        if ((rc = spmv_dispatch(h, h->mat[ITS_MAT_A], f, EPI_GS_FUSED, ITS_FMT_CSR_EXACT))) return rc;
+        h->ahead = true;
+        return finish_scalar(h, h->part[0], res_out, FIN_SQRT);
+    }
     SpmvArgs q; q.x = h->x; q.y = nullptr; q.b = h->b; q.part_sum = h->part[0];         // norm only
     if ((rc = solver_spmv(h, q, EPI_RESIDUAL))) return rc;                             // utility_funcs.hpp:444-447
     return finish_scalar(h, h->part[0], res_out, FIN_SQRT);
@@ -873,6 +917,12 @@ extern "C" int its_spmv_timed(its_handle *h, int which, const double *x_dev, dou
     if (with_dot == 1) { a.dotv = x_dev; a.part_sum = h->part[3]; }
     // measurement forms of the residual epilogue (r = b - A x with its norm): 2 = r stored, 3 = norm only
     if (with_dot == 2 || with_dot == 3) { epi = EPI_RESIDUAL; a.b = x_dev; a.part_sum = h->part[3]; if (with_dot == 3) a.y = nullptr; }
+    // 4..7 = the Jacobi / GS epilogues as the trips launch them (b := x): EPI_JACOBI_REF, EPI_GS_RHS, and their
+    // fused forms EPI_JACOBI_FUSED, EPI_GS_FUSED
+    if (with_dot >= 4 && with_dot <= 7) {
+        const int e[4] = {EPI_JACOBI_REF, EPI_GS_RHS, EPI_JACOBI_FUSED, EPI_GS_FUSED};
+        epi = e[with_dot - 4]; a.b = x_dev; a.part_sum = h->part[3];
+    }
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     for (int i = 0; i < reps; ++i) { int rc = spmv_dispatch(h, h->mat[which], a, epi, format); if (rc) return rc; }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));

@@ -79,7 +79,12 @@ static int ensure_plan(its_handle *h)
     if (!h->dist) {
         h->dist = new DistPlan;
         HIPCHK(h, hipSetDevice(h->device));
-        HIPCHK(h, hipStreamCreateWithFlags(&h->dist->cstream, hipStreamNonBlocking));
+        // the halo stream outranks the compute stream: pack finishes, then the exchange kernel and the interior
+        // SpMV become runnable together, and the (tiny) exchange must get its CUs first or a persistent SpMV
+        // grid would hold it back until the interior product is done
+        int prio_least = 0, prio_greatest = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->dist->cstream, hipStreamNonBlocking, prio_greatest));
         HIPCHK(h, hipEventCreateWithFlags(&h->dist->ev_pack, hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->dist->ev_halo, hipEventDisableTiming));
         HIPCHK(h, hipHostMalloc((void **)&h->dist->host_sc, 64 * sizeof(double), hipHostMallocDefault));

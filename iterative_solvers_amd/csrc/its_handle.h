@@ -54,6 +54,12 @@ struct its_handle {
     int rr_slot = 0;
 
     int solver = -1, precond = 0, jacobi_mode = 0, gs_order = 0;
+    // Jacobi / Gauss-Seidel trips read the matrix once: the pass that records the residual of the new iterate
+    // also produces the next trip's product of it (EPI_JACOBI_FUSED / EPI_GS_FUSED).  `ahead` = that product
+    // (Jacobi: the next iterate in x_b; GS: b - U x in tmp) is already there.  Option "fused_residual" = 0
+    // keeps the two separate launches (same bits).
+    int fused_residual = 1;
+    bool ahead = false;
     bool setup_done = false, residual_done = false;
     double last_residual = 0.0;
     // triangular sweep schedule (levels of L; colours when the matrix was colour-permuted)

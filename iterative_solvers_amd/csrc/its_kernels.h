@@ -23,7 +23,12 @@ enum SpmvEpilogue {
     EPI_RESIDUAL = 1,     // y = b - A x, + sum r^2 and max|r|        (kernels.hpp:670-726)
     EPI_JACOBI_SHIPPED = 2,  // out = (b - (x - D*(A x)))/D           (jacobi.hpp:191,41-62)
     EPI_JACOBI_REF = 3,   // out = (b - sum_{j!=i} a_ij x_j)/a_ii     (jacobi.hpp:65-93)
-    EPI_GS_RHS = 4        // y = b - U x                              (gauss_seidel.hpp:144,177)
+    EPI_GS_RHS = 4,       // y = b - U x                              (gauss_seidel.hpp:144,177)
+    // one pass over A, two in-order chains per row: the recorded residual norm of x (full chain, as
+    // EPI_RESIDUAL) AND the next trip's product of the same x (restricted chain).  Bit-identical to the two
+    // separate launches they replace; the trips below use them to read the matrix once per trip.
+    EPI_JACOBI_FUSED = 5, // out = EPI_JACOBI_REF of x, + sum (b - A x)^2 / max
+    EPI_GS_FUSED = 6      // y = b - (strictly upper part of A) x, + sum (b - A x)^2 / max
 };
 
 struct CsrDev {
@@ -47,6 +52,7 @@ struct CsrDev {
     // vector-CSR plan
     int lanes_per_row = 0;
     int max_row_len = 0;                      // longest row: > IRR_ROW_LEN selects the irregular-row exact kernel
+    int64_t n_upper = 0;                      // entries with col > row (what a matching crs_U must hold)
     // SELL-64-sigma image
     int sell_chunks = 0, sell_sigma = 0;
     int64_t sell_elems = 0;

@@ -54,6 +54,78 @@ template <int NT> __device__ __forceinline__ void st_d1(double *p, double v)
     if (NT & 2) __builtin_nontemporal_store(v, p); else *p = v;
 }
 
+// --------------------------------------------------------------------------------------
+// What the epilogues ask of the per-row walk, shared by every exact kernel below.
+//   chain_step   one entry of the row, in CRS order: `acc` is the epilogue's own chain (all entries; all but the
+//                diagonal for the Jacobi forms, jacobi.hpp:76-85; entries right of the diagonal for EPI_GS_FUSED),
+//                `acc2` the full chain of the fused forms (the recorded residual of the same x)
+//   row_finish   the value to store and the row's contribution to the partial sums
+// e0..e2 are the epilogue's per-row operands (epi_operands), loaded where the kernel's pipeline wants them.
+// --------------------------------------------------------------------------------------
+template <int EPI> struct EpiKind {
+    static constexpr bool skip_diag = EPI == EPI_JACOBI_REF || EPI == EPI_JACOBI_FUSED;
+    static constexpr bool upper_only = EPI == EPI_GS_FUSED;
+    static constexpr bool fused = EPI == EPI_JACOBI_FUSED || EPI == EPI_GS_FUSED;
+    static constexpr bool norm = EPI == EPI_RESIDUAL || fused;          // writes r^2 / max|r| partials
+    static constexpr bool needs_col = skip_diag || upper_only;
+};
+
+template <int EPI>
+__device__ __forceinline__ void chain_step(int c, int row, double v, double x, double &acc, double &acc2, double &diag)
+{
+    // An entry the chain leaves out enters it as fma(0, 0, acc) instead of a select on acc: acc starts at +0.0
+    // and round-to-nearest never makes it -0.0, so acc + (+0.0) returns acc bit for bit, and the selects sit on
+    // the operands, off the dependent chain (a select per entry on acc itself made the EPI_GS_FUSED walk of a
+    // long row 1.4x slower).
+    if (EpiKind<EPI>::fused) acc2 = fma(v, x, acc2);
+    if (EpiKind<EPI>::skip_diag) {
+        const bool dg = c == row;
+        diag = dg ? v : diag;
+        acc = fma(dg ? 0.0 : v, dg ? 0.0 : x, acc);
+    } else if (EpiKind<EPI>::upper_only) {
+        const bool up = c > row;
+        acc = fma(up ? v : 0.0, up ? x : 0.0, acc);
+    } else {
+        acc = fma(v, x, acc);
+    }
+}
+
+template <int EPI, bool DOT>
+__device__ __forceinline__ void epi_operands(const SpmvArgs &a, int row, double &e0, double &e1, double &e2)
+{
+    if (EPI == EPI_STORE && DOT) e0 = a.dotv[row];
+    if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) e0 = a.b[row];
+    if (EPI == EPI_JACOBI_SHIPPED) { e0 = a.D[row]; e1 = a.x[row]; e2 = a.b[row]; }
+}
+
+template <int EPI, bool DOT>
+__device__ __forceinline__ double row_finish(double acc, double acc2, double diag, double e0, double e1, double e2,
+                                             double &lane_sum, double &lane_max)
+{
+    double outv;
+    if (EPI == EPI_STORE) {
+        outv = acc;
+        if (DOT) lane_sum = fma(acc, e0, lane_sum);
+    } else if (EPI == EPI_RESIDUAL) {
+        outv = e0 - acc;
+        lane_sum = fma(outv, outv, lane_sum);
+        lane_max = fmax(lane_max, fabs(outv));
+    } else if (EPI == EPI_JACOBI_SHIPPED) {
+        const double adj = fma(-e0, acc, e1);
+        outv = (e2 - adj) / e0;
+    } else if (EPI == EPI_JACOBI_REF || EPI == EPI_JACOBI_FUSED) {
+        outv = (e0 - acc) / diag;
+    } else {                                        // EPI_GS_RHS, EPI_GS_FUSED
+        outv = fma(-1.0, acc, e0);
+    }
+    if (EpiKind<EPI>::fused) {
+        const double r = e0 - acc2;
+        lane_sum = fma(r, r, lane_sum);
+        lane_max = fmax(lane_max, fabs(r));
+    }
+    return outv;
+}
+
 // IDX: stream the 1-byte column-offset dictionary index instead of col (see spmv_stream4_kernel, CMP = 1)
 template <int EPI, bool DOT, bool IDX>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
@@ -143,7 +215,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         int4 dnn = blk_desc[min(rb + 2 * rstep, rb_last)]; dnn.y &= 0xffff;
         const int rs = d.x, nr = d.y;
         const int row = rs + t;
-        double acc = 0.0, diag = 0.0;
+        double acc = 0.0, acc2 = 0.0, diag = 0.0;
         const bool lng = d.w - d.z > SPMV_NNZ_MAX;
         if (!lng) {
             if (!have) S2_ISSUE(d);
@@ -167,12 +239,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
 #pragma unroll
                     for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (j + u < j1) {
-                            if (EPI == EPI_JACOBI_REF && c[u] == row) diag = v[u];
-                            else acc = fma(v[u], xv[u], acc);
-                        }
-                    }
+                    for (int u = 0; u < 8; ++u)
+                        if (j + u < j1) chain_step<EPI>(c[u], row, v[u], xv[u], acc, acc2, diag);
                 }
             }
         } else {
@@ -192,32 +260,17 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
                 if (t == 0) {
                     for (int j = c0 - base; j < c1 - base; ++j) {
                         const int cc = s_col[cur][j];
-                        const double vv = s_val[cur][j];
-                        if (EPI == EPI_JACOBI_REF && cc == row) diag = vv;
-                        else acc = fma(vv, a.x[cc], acc);
+                        chain_step<EPI>(cc, row, s_val[cur][j], a.x[cc], acc, acc2, diag);
                     }
                 }
             }
             __syncthreads();
         }
         if (t < nr) {
-            if (EPI == EPI_STORE) {
-                st_d1<NT>(a.y + row, acc);
-                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
-            } else if (EPI == EPI_RESIDUAL) {
-                const double r = a.b[row] - acc;
-                if (a.y) st_d1<NT>(a.y + row, r);
-                lane_sum = fma(r, r, lane_sum);
-                lane_max = fmax(lane_max, fabs(r));
-            } else if (EPI == EPI_JACOBI_SHIPPED) {
-                const double dd = a.D[row];
-                const double adj = fma(-dd, acc, a.x[row]);
-                a.y[row] = (a.b[row] - adj) / dd;
-            } else if (EPI == EPI_JACOBI_REF) {
-                a.y[row] = (a.b[row] - acc) / diag;
-            } else if (EPI == EPI_GS_RHS) {
-                a.y[row] = fma(-1.0, acc, a.b[row]);
-            }
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+            epi_operands<EPI, DOT>(a, row, e0, e1, e2);
+            const double outv = row_finish<EPI, DOT>(acc, acc2, diag, e0, e1, e2, lane_sum, lane_max);
+            if (a.y) st_d1<NT>(a.y + row, outv);             // y == nullptr: only the norm is wanted
         }
         cur ^= 1;
         d = dn; dn = dnn;
@@ -225,7 +278,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
 #undef S2_ISSUE
 #undef S2_DECODE
 #undef S2_COMMIT
-    if (DOT || EPI == EPI_RESIDUAL) {
+    if (DOT || EpiKind<EPI>::norm) {
         const double bs = block_sum(lane_sum, s_red);
         if (t == 0 && a.part_sum) {
             if (a.part_accum) a.part_sum[blockIdx.x] += bs;
@@ -234,7 +287,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
                 for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
             }
         }
-        if (EPI == EPI_RESIDUAL && a.part_max) {
+        if (EpiKind<EPI>::norm && a.part_max) {
             const double bm = block_max(lane_max, s_red);
             if (t == 0) {
                 if (a.part_accum) a.part_max[blockIdx.x] = fmax(a.part_max[blockIdx.x], bm);
@@ -363,10 +416,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
     _Pragma("unroll") for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
 #define S4_BATCH_FMA()                                                                    \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                       \
-        if (j + u < j1) {                                                                 \
-            if (EPI == EPI_JACOBI_REF && c[u] == row) diag = v[u];                        \
-            else acc = fma(v[u], xv[u], acc);                                             \
-        }                                                                                 \
+        if (j + u < j1) chain_step<EPI>(c[u], row, v[u], xv[u], acc, acc2, diag);         \
     }
 
 #define S4_BODY(R, buf)                                                                                   \
@@ -380,12 +430,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         __syncthreads();                                                                                  \
         if (pend_row >= 0) { a.y[pend_row] = pend_val; pend_row = -1; }                                   \
         double e0 = 0.0, e1 = 0.0, e2 = 0.0;                                                              \
-        if (t < nr) {                                                                                     \
-            if (EPI == EPI_STORE && DOT) e0 = a.dotv[row];                                                \
-            if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS) e0 = a.b[row];         \
-            if (EPI == EPI_JACOBI_SHIPPED) { e0 = a.D[row]; e1 = a.x[row]; e2 = a.b[row]; }               \
-        }                                                                                                 \
-        double acc = 0.0, diag = 0.0;                                                                     \
+        if (t < nr) epi_operands<EPI, DOT>(a, row, e0, e1, e2);                                           \
+        double acc = 0.0, acc2 = 0.0, diag = 0.0;                                                         \
         int c[8]; double v[8], xv[8];                                                                     \
         int j = 0, j1 = 0;                                                                                \
         if (!lng) {                                                                                       \
@@ -411,9 +457,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
                 if (t == 0) {                                                                             \
                     for (int q = c0 - base; q < c1 - base; ++q) {                                         \
                         const int cc = s_col[buf][q];                                                     \
-                        const double vv = s_val[buf][q];                                                  \
-                        if (EPI == EPI_JACOBI_REF && cc == row) diag = vv;                                \
-                        else acc = fma(vv, a.x[cc], acc);                                                 \
+                        chain_step<EPI>(cc, row, s_val[buf][q], a.x[cc], acc, acc2, diag);                \
                     }                                                                                     \
                 }                                                                                         \
             }                                                                                             \
@@ -423,22 +467,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         S4_ISSUE(R, dC);                                                                                  \
         S4_BATCH_FMA()                                                                                    \
         if (t < nr) {                                                                                     \
-            double outv;                                                                                  \
-            if (EPI == EPI_STORE) {                                                                       \
-                outv = acc;                                                                               \
-                if (DOT) lane_sum = fma(acc, e0, lane_sum);                                               \
-            } else if (EPI == EPI_RESIDUAL) {                                                             \
-                outv = e0 - acc;                                                                          \
-                lane_sum = fma(outv, outv, lane_sum);                                                     \
-                lane_max = fmax(lane_max, fabs(outv));                                                    \
-            } else if (EPI == EPI_JACOBI_SHIPPED) {                                                       \
-                const double adj = fma(-e0, acc, e1);                                                     \
-                outv = (e2 - adj) / e0;                                                                   \
-            } else if (EPI == EPI_JACOBI_REF) {                                                           \
-                outv = (e0 - acc) / diag;                                                                 \
-            } else {                                                                                      \
-                outv = fma(-1.0, acc, e0);                                                                \
-            }                                                                                             \
+            const double outv = row_finish<EPI, DOT>(acc, acc2, diag, e0, e1, e2, lane_sum, lane_max);    \
             if (a.y) { pend_val = outv; pend_row = row; }   /* y == nullptr: only the norm is wanted */   \
         }                                                                                                 \
         dA = dB; dB = dC; dC = dD;                                                                        \
@@ -458,7 +487,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         }
         if (pend_row >= 0) a.y[pend_row] = pend_val;
     }
-    if (DOT || EPI == EPI_RESIDUAL) {
+    if (DOT || EpiKind<EPI>::norm) {
         const double bs = block_sum(lane_sum, s_red);
         if (t == 0 && a.part_sum) {
             if (a.part_accum) a.part_sum[blockIdx.x] += bs;
@@ -467,7 +496,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
                 for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
             }
         }
-        if (EPI == EPI_RESIDUAL && a.part_max) {
+        if (EpiKind<EPI>::norm && a.part_max) {
             const double bm = block_max(lane_max, s_red);
             if (t == 0) {
                 if (a.part_accum) a.part_max[blockIdx.x] = fmax(a.part_max[blockIdx.x], bm);
@@ -542,9 +571,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream5_kernel(
         if (t < Gs.nr) {                                                                  \
             const int base_ = (d).z & ~3;                                                 \
             Gs.j = s_rp[buf][t] - base_; Gs.j1 = s_rp[buf][t + 1] - base_;                \
-            if (EPI == EPI_STORE && DOT) Gs.e0 = a.dotv[Gs.row];                          \
-            if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS) Gs.e0 = a.b[Gs.row]; \
-            if (EPI == EPI_JACOBI_SHIPPED) { Gs.e0 = a.D[Gs.row]; Gs.e1 = a.x[Gs.row]; Gs.e2 = a.b[Gs.row]; } \
+            epi_operands<EPI, DOT>(a, Gs.row, Gs.e0, Gs.e1, Gs.e2);                       \
         }                                                                                 \
         _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                   \
             const bool ok_ = Gs.j + u < Gs.j1;                                            \
@@ -557,30 +584,11 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream5_kernel(
     // the in-order chain of the row block whose gathers sit in Gs, its epilogue, result parked
 #define S5_FINISH(Gs)                                                                     \
     do {                                                                                  \
-        double acc = 0.0, diag = 0.0;                                                     \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                   \
-            if (Gs.j + u < Gs.j1) {                                                       \
-                if (EPI == EPI_JACOBI_REF && Gs.c[u] == Gs.row) diag = Gs.v[u];           \
-                else acc = fma(Gs.v[u], Gs.x[u], acc);                                    \
-            }                                                                             \
-        }                                                                                 \
+        double acc = 0.0, acc2 = 0.0, diag = 0.0;                                         \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u)                                     \
+            if (Gs.j + u < Gs.j1) chain_step<EPI>(Gs.c[u], Gs.row, Gs.v[u], Gs.x[u], acc, acc2, diag); \
         if (t < Gs.nr) {                                                                  \
-            double outv;                                                                  \
-            if (EPI == EPI_STORE) {                                                       \
-                outv = acc;                                                               \
-                if (DOT) lane_sum = fma(acc, Gs.e0, lane_sum);                            \
-            } else if (EPI == EPI_RESIDUAL) {                                             \
-                outv = Gs.e0 - acc;                                                       \
-                lane_sum = fma(outv, outv, lane_sum);                                     \
-                lane_max = fmax(lane_max, fabs(outv));                                    \
-            } else if (EPI == EPI_JACOBI_SHIPPED) {                                       \
-                const double adj = fma(-Gs.e0, acc, Gs.e1);                               \
-                outv = (Gs.e2 - adj) / Gs.e0;                                             \
-            } else if (EPI == EPI_JACOBI_REF) {                                           \
-                outv = (Gs.e0 - acc) / diag;                                              \
-            } else {                                                                      \
-                outv = fma(-1.0, acc, Gs.e0);                                             \
-            }                                                                             \
+            const double outv = row_finish<EPI, DOT>(acc, acc2, diag, Gs.e0, Gs.e1, Gs.e2, lane_sum, lane_max); \
             if (a.y) { pend_val = outv; pend_row = Gs.row; }                              \
         }                                                                                 \
     } while (0)
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream5_kernel(
 #undef S5_LOADGATHER
 #undef S5_FINISH
 #undef S5_STEP
-    if (DOT || EPI == EPI_RESIDUAL) {
+    if (DOT || EpiKind<EPI>::norm) {
         const double bs = block_sum(lane_sum, s_red);
         if (t == 0 && a.part_sum) {
             if (a.part_accum) a.part_sum[blockIdx.x] += bs;
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream5_kernel(
                 for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
             }
         }
-        if (EPI == EPI_RESIDUAL && a.part_max) {
+        if (EpiKind<EPI>::norm && a.part_max) {
             const double bm = block_max(lane_max, s_red);
             if (t == 0) {
                 if (a.part_accum) a.part_max[blockIdx.x] = fmax(a.part_max[blockIdx.x], bm);
@@ -665,8 +673,9 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream5_kernel(
 // exceeds IRR_ROW_LEN (CsrDev::max_row_len); rows longer than the LDS capacity are streamed in
 // chunks with lane 0 carrying the chain across chunks.
 // --------------------------------------------------------------------------------------
+// 5 workgroups per CU (LDS footprint) = 5 waves per SIMD: keep the register count within 512 / 5
 template <int EPI, bool DOT>
-__global__ __launch_bounds__(ITS_BLOCK) void spmv_irr_kernel(
+__global__ __launch_bounds__(ITS_BLOCK, 5) void spmv_irr_kernel(
     int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
     const int *__restrict__ col, const double *__restrict__ val, int n_rows, SpmvArgs a)
 {
@@ -739,18 +748,13 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_irr_kernel(
             double vv[8], xx[8]; int cc[8];                                               \
             _Pragma("unroll") for (int u = 0; u < 8; ++u) {                               \
                 vv[u] = s_val[j + u]; xx[u] = s_xg[j + u];                                \
-                if (EPI == EPI_JACOBI_REF) cc[u] = s_col[j + u];                          \
+                cc[u] = EpiKind<EPI>::needs_col ? s_col[j + u] : 0;                       \
             }                                                                             \
-            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                               \
-                if (EPI == EPI_JACOBI_REF && cc[u] == row) diag = vv[u];                  \
-                else acc = fma(vv[u], xx[u], acc);                                        \
-            }                                                                             \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u)                                 \
+                chain_step<EPI>(cc[u], row, vv[u], xx[u], acc, acc2, diag);               \
         }                                                                                 \
-        for (; j < je_; ++j) {                                                            \
-            const double vv = s_val[j];                                                   \
-            if (EPI == EPI_JACOBI_REF && s_col[j] == row) diag = vv;                      \
-            else acc = fma(vv, s_xg[j], acc);                                             \
-        }                                                                                 \
+        for (; j < je_; ++j)                                                              \
+            chain_step<EPI>(EpiKind<EPI>::needs_col ? s_col[j] : 0, row, s_val[j], s_xg[j], acc, acc2, diag); \
     }
 
     for (int rb = rb0; rb < rb1; rb += rstep) {
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_irr_kernel(
         const int rbn = rb + rstep;
         int4 dn = make_int4(0, 0, 0, 0);
         if (rbn < rb1) dn = blk_desc[rbn];
-        double acc = 0.0, diag = 0.0;
+        double acc = 0.0, acc2 = 0.0, diag = 0.0;
         int my_rp = 0;
         if (t < nr) my_rp = rp[d.x + t];
         for (int c0 = d.z; ; c0 += SPMV_NNZ_MAX) {
@@ -783,29 +787,16 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_irr_kernel(
             if (c1 >= d.w) break;
         }
         if (t < nr) {
-            if (EPI == EPI_STORE) {
-                a.y[row] = acc;
-                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
-            } else if (EPI == EPI_RESIDUAL) {
-                const double r = a.b[row] - acc;
-                if (a.y) a.y[row] = r;                       // y == nullptr: only the norm is wanted
-                lane_sum = fma(r, r, lane_sum);
-                lane_max = fmax(lane_max, fabs(r));
-            } else if (EPI == EPI_JACOBI_SHIPPED) {
-                const double dd = a.D[row];
-                const double adj = fma(-dd, acc, a.x[row]);
-                a.y[row] = (a.b[row] - adj) / dd;
-            } else if (EPI == EPI_JACOBI_REF) {
-                a.y[row] = (a.b[row] - acc) / diag;
-            } else if (EPI == EPI_GS_RHS) {
-                a.y[row] = fma(-1.0, acc, a.b[row]);
-            }
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+            epi_operands<EPI, DOT>(a, row, e0, e1, e2);
+            const double outv = row_finish<EPI, DOT>(acc, acc2, diag, e0, e1, e2, lane_sum, lane_max);
+            if (a.y) a.y[row] = outv;                        // y == nullptr: only the norm is wanted
         }
     }
 #undef IRR_ISSUE
 #undef IRR_PARK
 #undef IRR_CHAIN
-    if (DOT || EPI == EPI_RESIDUAL) {
+    if (DOT || EpiKind<EPI>::norm) {
         const double bs = block_sum(lane_sum, s_red);
         if (t == 0 && a.part_sum) {
             if (a.part_accum) a.part_sum[blockIdx.x] += bs;
@@ -814,7 +805,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_irr_kernel(
                 for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
             }
         }
-        if (EPI == EPI_RESIDUAL && a.part_max) {
+        if (EpiKind<EPI>::norm && a.part_max) {
             const double bm = block_max(lane_max, s_red);
             if (t == 0) {
                 if (a.part_accum) a.part_max[blockIdx.x] = fmax(a.part_max[blockIdx.x], bm);
@@ -890,6 +881,8 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
         case EPI_JACOBI_SHIPPED: ITS_LAUNCHI(EPI_JACOBI_SHIPPED, false); break;
         case EPI_JACOBI_REF: ITS_LAUNCHI(EPI_JACOBI_REF, false); break;
         case EPI_GS_RHS: ITS_LAUNCHI(EPI_GS_RHS, false); break;
+        case EPI_JACOBI_FUSED: ITS_LAUNCHI(EPI_JACOBI_FUSED, false); break;
+        case EPI_GS_FUSED: ITS_LAUNCHI(EPI_GS_FUSED, false); break;
         }
 #undef ITS_LAUNCHI
         return;
@@ -923,6 +916,8 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
         case EPI_JACOBI_SHIPPED: ITS_LAUNCH5(EPI_JACOBI_SHIPPED, false); break;
         case EPI_JACOBI_REF: ITS_LAUNCH5(EPI_JACOBI_REF, false); break;
         case EPI_GS_RHS: ITS_LAUNCH5(EPI_GS_RHS, false); break;
+        case EPI_JACOBI_FUSED: ITS_LAUNCH5(EPI_JACOBI_FUSED, false); break;
+        case EPI_GS_FUSED: ITS_LAUNCH5(EPI_GS_FUSED, false); break;
         }
 #undef ITS_LAUNCH5
 #undef ITS_LAUNCH5C
@@ -931,13 +926,7 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
     // measured (256^3 7-pt, offset stream): v4 wins inside the CG loop (0.511 vs 0.522 ms per trip), v2 wins for
     // every other epilogue (plain 0.303 vs 0.316 ms, Jacobi trip 0.620 vs 0.672 ms, norm-only residual 0.245 vs 0.299)
     if (g_spmv_variant == 4 && A.max_row_len <= 8 && epi == EPI_STORE && a.dotv) {
-        switch (epi) {
-        case EPI_STORE: if (a.dotv) ITS_LAUNCH4(EPI_STORE, true); else ITS_LAUNCH4(EPI_STORE, false); break;
-        case EPI_RESIDUAL: ITS_LAUNCH4(EPI_RESIDUAL, false); break;
-        case EPI_JACOBI_SHIPPED: ITS_LAUNCH4(EPI_JACOBI_SHIPPED, false); break;
-        case EPI_JACOBI_REF: ITS_LAUNCH4(EPI_JACOBI_REF, false); break;
-        case EPI_GS_RHS: ITS_LAUNCH4(EPI_GS_RHS, false); break;
-        }
+        ITS_LAUNCH4(EPI_STORE, true);
         return;
     }
 #undef ITS_LAUNCH4
@@ -947,6 +936,8 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
     case EPI_JACOBI_SHIPPED: ITS_LAUNCH2(EPI_JACOBI_SHIPPED, false); break;
     case EPI_JACOBI_REF: ITS_LAUNCH2(EPI_JACOBI_REF, false); break;
     case EPI_GS_RHS: ITS_LAUNCH2(EPI_GS_RHS, false); break;
+    case EPI_JACOBI_FUSED: ITS_LAUNCH2(EPI_JACOBI_FUSED, false); break;
+    case EPI_GS_FUSED: ITS_LAUNCH2(EPI_GS_FUSED, false); break;
     }
 #undef ITS_LAUNCH2
 }

@@ -170,3 +170,31 @@ def test_gauss_seidel_multicolor(name):
     check_history(ref, args)
     x_ref = np.empty(n); x_ref[perm] = ref["x_star"]
     assert np.max(np.abs(xs - x_ref)) <= 1e-12 * max(1.0, np.max(np.abs(x_ref)))
+
+
+@pytest.mark.parametrize("valdict", [0, 1])
+@pytest.mark.parametrize("name", ["lap3d_16", "cd27_6", "pl_200", "pl_5000"])
+@pytest.mark.parametrize("flag", ["-j", "-gs"])
+def test_one_matrix_pass_per_trip_is_bit_identical(flag, name, valdict):
+    """Jacobi / GS trips read A once: the residual pass also produces the next trip's product of the same x
+    (EPI_JACOBI_FUSED / EPI_GS_FUSED, second in-order chain).  Same bits as the separate launches
+    (option fused_residual = 0), on every exact kernel (stream, value-dictionary, irregular rows)."""
+    rp, col, val = MATRICES[name]()
+    n = len(rp) - 1
+    out = []
+    for fused in (1, 0):
+        args = S.Args(S.CLI_SOLVER[flag], S.LoopParams(max_iters=60, tol=1e-13), S.Flags(), "", "none")
+        sol = S.Solver(args.solver_type, device=0, jacobi_mode=1)
+        try:
+            sol.handle.set_option("fused_residual", fused)
+            sol.handle.set_option("spmv_valdict", valdict)
+            S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+            S.solve(args, sol)
+            out.append((args.normed_residuals[:args.loop_params.residual_count].copy(), sol.x_star.copy(),
+                        args.loop_params.iter_count))
+        finally:
+            sol.handle.set_option("spmv_valdict", 0)
+            sol.handle.close()
+    assert out[0][2] == out[1][2] and out[0][2] > 3
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])

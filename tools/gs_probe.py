@@ -10,6 +10,7 @@ order = capi.GS_MULTICOLOR if (len(sys.argv) < 3 or sys.argv[2] == "mc") else ca
 rp, col, val = matgen.powerlaw(n)
 args = S.Args("gauss-seidel", S.LoopParams(max_iters=10**9, tol=0.0))
 sol = S.Solver("gauss-seidel", device=0, gs_order=order)
+sol.handle.set_option("fused_residual", int(os.environ.get("FUSED", "1")))
 S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
 h = sol.handle
 for it in range(2): h.iterate(it)
