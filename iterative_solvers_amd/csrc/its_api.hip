@@ -58,7 +58,7 @@ extern "C" int its_destroy(its_handle *h)
     dfree(h->p); dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
     for (auto &e : h->prof_ev) (void)hipEventDestroy(e);
     for (auto &p : h->part) dfree(p);
-    dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows);
+    dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows); dfree(h->sweep_desc);
     if (h->pinned) (void)hipHostFree(h->pinned);
     (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
     (void)hipStreamDestroy(h->stream);
@@ -289,6 +289,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->gmres_givens = value;
         return ITS_OK;
     }
+    if (!strcmp(name, "sweep_stream")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_stream: 0 or 1");
+        h->sweep_stream = value;
+        return ITS_OK;
+    }
     if (!strcmp(name, "fused_residual")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "fused_residual: 0 or 1");
         h->fused_residual = value;
@@ -408,6 +413,23 @@ static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc)
         lev[i] = l; nl = std::max(nl, l + 1);
     }
     if (n == 0) nl = 0;
+    // Alternative schedule: cut the rows, in order, into contiguous ranges without internal dependencies (a new
+    // range starts at the first row that reads a row of the current one).  For a colour-by-colour ordering this
+    // recovers the colours (dependency levels would scatter a colour's rows over earlier levels); for a natural
+    // ordering it degenerates to about one range per row.  Either schedule gives every row the same operands
+    // (everything it reads was finished by an earlier launch), so the choice is free: ranges win when they are
+    // not many more than the dependency levels, because a range is swept like an SpMV (below).
+    {
+        std::vector<int> rng(n, 0);
+        int nr = n ? 1 : 0, start = 0;
+        for (int i = 0; i < n; ++i) {
+            bool dep = false;
+            for (int k = Lp[i]; k < Lp[i + 1] && !dep; ++k) dep = Lc[k] >= start;
+            if (dep) { start = i; ++nr; }
+            rng[i] = nr - 1;
+        }
+        if (nr <= 2 * nl + 16) { lev.swap(rng); nl = nr; }
+    }
     h->n_levels = nl;
     h->level_ptr.assign(nl + 1, 0);
     for (int i = 0; i < n; ++i) ++h->level_ptr[lev[i] + 1];
@@ -420,6 +442,56 @@ static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc)
     dfree(h->level_rows);
     if (dalloc(h, &h->level_rows, n)) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(h->level_rows, rows.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    // A level that is one contiguous range of many rows (a colour of the multicolour ordering) is an SpMV over
+    // those rows of L with the sweep's epilogue: it gets row-block descriptors of its own (blocks end at the
+    // level's end) and runs on the exact stream kernels.  Levels of the natural order are scattered rows: they
+    // keep the level-list kernel.
+    h->level_desc_first.assign(nl, 0); h->level_desc_count.assign(nl, 0);
+    std::vector<int4> desc;
+    std::vector<int> blk;
+    for (int l = 0; l < nl; ++l) {
+        const int b0 = h->level_ptr[l], cnt = h->level_ptr[l + 1] - b0;
+        if (cnt < SWEEP_STREAM_MIN) continue;
+        int lo = rows[b0], hi = rows[b0];
+        for (int k = b0; k < b0 + cnt; ++k) { lo = std::min(lo, rows[k]); hi = std::max(hi, rows[k]); }
+        if (hi - lo + 1 != cnt) continue;
+        build_stream_plan(cnt, Lp + lo, blk);              // row indices relative to lo
+        h->level_desc_first[l] = (int)desc.size();
+        const int nbl = h->level_desc_count[l] = (int)blk.size() - 1;
+        std::vector<int4> hubs, rest;
+        for (size_t i = 0; i + 1 < blk.size(); ++i) {
+            const int r0 = lo + blk[i], r1 = lo + blk[i + 1];
+            int longest = 0;
+            for (int r = r0; r < r1; ++r) longest = std::max(longest, Lp[r + 1] - Lp[r]);
+            const int4 d4 = make_int4(r0, (r1 - r0) | (std::min(longest, 0x7fff) << 16), Lp[r0], Lp[r1]);
+            (longest >= SWEEP_HUB ? hubs : rest).push_back(d4);
+        }
+        // A level lasts at least as long as the serial walk of its longest row.  Blocks are independent, so the
+        // ones holding such rows go first: under the kernels' XCD-interleaved map (workgroup j of XCD e walks
+        // blocks X0(e) + j, X0(e) + j + G/8, ...) the front of each eighth of the list is what the workgroups
+        // start with, so every long walk begins at once instead of behind a queue of short rows.
+        if (!hubs.empty() && nbl >= 64 && (int)hubs.size() <= nbl / 2) {
+            std::sort(hubs.begin(), hubs.end(), [](const int4 &a, const int4 &b) { return (a.y >> 16) > (b.y >> 16); });
+            size_t ir = 0;
+            for (int e = 0; e < 8; ++e) {
+                const int X0 = (int)(((int64_t)e * nbl) / 8), X1 = (int)(((int64_t)(e + 1) * nbl) / 8);
+                int filled = 0;
+                for (size_t k = e; k < hubs.size() && filled < X1 - X0; k += 8, ++filled) desc.push_back(hubs[k]);
+                for (; filled < X1 - X0; ++filled) desc.push_back(rest[ir++]);
+            }
+        } else {
+            // (original order)
+            std::vector<int4> all(hubs.size() + rest.size());
+            std::merge(hubs.begin(), hubs.end(), rest.begin(), rest.end(), all.begin(),
+                       [](const int4 &a, const int4 &b) { return a.x < b.x; });
+            desc.insert(desc.end(), all.begin(), all.end());
+        }
+    }
+    dfree(h->sweep_desc);
+    if (!desc.empty()) {
+        if (dalloc(h, &h->sweep_desc, desc.size())) return ITS_EHIP;
+        HIPCHK(h, hipMemcpy(h->sweep_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
     return ITS_OK;
 }
 
@@ -429,7 +501,12 @@ static int sweep(its_handle *h, double *x, const double *rhs)
     const CsrDev &L = h->mat[ITS_MAT_L];
     for (int l = 0; l < h->n_levels; ++l) {
         const int cnt = h->level_ptr[l + 1] - h->level_ptr[l];
-        launch_sweep_level(L, h->level_rows + h->level_ptr[l], cnt, h->level_nshort[l], x, rhs, h->D, h->stream);
+        if (h->level_desc_count[l] > 0 && h->sweep_stream) {
+            SpmvArgs a; a.x = x; a.y = x; a.b = rhs; a.D = h->D;   // rows of a level never read each other's x
+            launch_spmv_exact_desc(L, h->sweep_desc + h->level_desc_first[l], h->level_desc_count[l], a, EPI_SWEEP, 0, h->stream);
+        } else {
+            launch_sweep_level(L, h->level_rows + h->level_ptr[l], cnt, h->level_nshort[l], x, rhs, h->D, h->stream);
+        }
     }
     HIPCHK(h, hipGetLastError());
     return ITS_OK;

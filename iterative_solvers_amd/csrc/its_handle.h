@@ -65,6 +65,11 @@ struct its_handle {
     // triangular sweep schedule (levels of L; colours when the matrix was colour-permuted)
     std::vector<int> level_ptr;           // host offsets into level_rows
     std::vector<int> level_nshort;            // rows of each level with <= SWEEP_SHORT entries in L (listed first)
+    // levels whose rows are one contiguous range and large (the colours of a multicolour ordering) are swept by
+    // the exact stream kernels (EPI_SWEEP) over their own row-block descriptors of L
+    int4 *sweep_desc = nullptr;                  // device, all such levels back to back
+    std::vector<int> level_desc_first, level_desc_count;   // per level; count 0 = level-list kernel
+    int sweep_stream = 1;                        // option "sweep_stream": 0 = level-list kernel for every level
     int *level_rows = nullptr;            // device
     int n_levels = 0;
     // multicolour permutation (gs_order == ITS_GS_MULTICOLOR): new index -> old index

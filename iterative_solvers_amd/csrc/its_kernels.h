@@ -28,7 +28,10 @@ enum SpmvEpilogue {
     // EPI_RESIDUAL) AND the next trip's product of the same x (restricted chain).  Bit-identical to the two
     // separate launches they replace; the trips below use them to read the matrix once per trip.
     EPI_JACOBI_FUSED = 5, // out = EPI_JACOBI_REF of x, + sum (b - A x)^2 / max
-    EPI_GS_FUSED = 6      // y = b - (strictly upper part of A) x, + sum (b - A x)^2 / max
+    EPI_GS_FUSED = 6,     // y = b - (strictly upper part of A) x, + sum (b - A x)^2 / max
+    // one dependency level of the triangular sweep whose rows are a contiguous range (a colour of the
+    // multicolour ordering): x_i = (b_i - sum_j L_ij x_j) / D_i, y aliases x   (kernels.hpp:460-472)
+    EPI_SWEEP = 7
 };
 
 struct CsrDev {
@@ -65,7 +68,7 @@ struct SpmvArgs {
     const double *x = nullptr;     // gathered vector
     double *y = nullptr;           // output vector
     const double *b = nullptr;     // rhs for residual / Jacobi / GS epilogues
-    const double *D = nullptr;     // diagonal for EPI_JACOBI_SHIPPED
+    const double *D = nullptr;     // diagonal for EPI_JACOBI_SHIPPED and EPI_SWEEP
     const double *dotv = nullptr;  // if set: part_sum[g] = sum_i (A x)_i * dotv_i   (EPI_STORE only)
     double *part_sum = nullptr;    // ITS_NPART partial sums (dot, or r^2 for EPI_RESIDUAL)
     double *part_max = nullptr;    // ITS_NPART partial max|r| (EPI_RESIDUAL, optional)
@@ -131,6 +134,8 @@ void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t
 // Gauss-Seidel / triangular sweeps (kernels.hpp:451-473) by dependency level or colour.
 // rows[] lists the rows of one level; x[i] = (rhs[i] - sum_j L_ij x_j) / D[i], in-order fma.
 // ---------------------------------------------------------------------------------------
+constexpr int SWEEP_STREAM_MIN = 4096;    // a contiguous level of at least this many rows runs on the exact SpMV kernels
+constexpr int SWEEP_HUB = 512;            // a row of L this long is started first in its level
 constexpr int SWEEP_SHORT = 16;            // rows of L up to this length take one lane, longer ones one wave
 // rows[0, n_short) must be the short rows of the level, rows[n_short, n_level_rows) the long ones
 void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int n_short, double *x,

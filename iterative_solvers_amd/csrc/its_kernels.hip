@@ -96,6 +96,7 @@ __device__ __forceinline__ void epi_operands(const SpmvArgs &a, int row, double 
     if (EPI == EPI_STORE && DOT) e0 = a.dotv[row];
     if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) e0 = a.b[row];
     if (EPI == EPI_JACOBI_SHIPPED) { e0 = a.D[row]; e1 = a.x[row]; e2 = a.b[row]; }
+    if (EPI == EPI_SWEEP) { e0 = a.b[row]; e1 = a.D[row]; }
 }
 
 template <int EPI, bool DOT>
@@ -115,6 +116,8 @@ __device__ __forceinline__ double row_finish(double acc, double acc2, double dia
         outv = (e2 - adj) / e0;
     } else if (EPI == EPI_JACOBI_REF || EPI == EPI_JACOBI_FUSED) {
         outv = (e0 - acc) / diag;
+    } else if (EPI == EPI_SWEEP) {
+        outv = (e0 - acc) / e1;
     } else {                                        // EPI_GS_RHS, EPI_GS_FUSED
         outv = fma(-1.0, acc, e0);
     }
@@ -883,6 +886,7 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
         case EPI_GS_RHS: ITS_LAUNCHI(EPI_GS_RHS, false); break;
         case EPI_JACOBI_FUSED: ITS_LAUNCHI(EPI_JACOBI_FUSED, false); break;
         case EPI_GS_FUSED: ITS_LAUNCHI(EPI_GS_FUSED, false); break;
+        case EPI_SWEEP: ITS_LAUNCHI(EPI_SWEEP, false); break;
         }
 #undef ITS_LAUNCHI
         return;
@@ -918,6 +922,7 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
         case EPI_GS_RHS: ITS_LAUNCH5(EPI_GS_RHS, false); break;
         case EPI_JACOBI_FUSED: ITS_LAUNCH5(EPI_JACOBI_FUSED, false); break;
         case EPI_GS_FUSED: ITS_LAUNCH5(EPI_GS_FUSED, false); break;
+        case EPI_SWEEP: ITS_LAUNCH5(EPI_SWEEP, false); break;
         }
 #undef ITS_LAUNCH5
 #undef ITS_LAUNCH5C
@@ -938,6 +943,7 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
     case EPI_GS_RHS: ITS_LAUNCH2(EPI_GS_RHS, false); break;
     case EPI_JACOBI_FUSED: ITS_LAUNCH2(EPI_JACOBI_FUSED, false); break;
     case EPI_GS_FUSED: ITS_LAUNCH2(EPI_GS_FUSED, false); break;
+    case EPI_SWEEP: ITS_LAUNCH2(EPI_SWEEP, false); break;
     }
 #undef ITS_LAUNCH2
 }
@@ -1375,22 +1381,20 @@ void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t
 // x_i = (rhs_i - sum_j L_ij x_j) / D_i with the reference's in-order fused chain
 // (kernels.hpp:460-472).  Rows of one level never read each other.
 // ======================================================================================
-// Short rows (<= SWEEP_SHORT entries, listed first) take one lane each, gathers eight at a time, in the
-// first `short_blocks` workgroups.  Every longer row gets a whole wave of the remaining workgroups:
-// SWEEP_CHUNK entries of col/val are loaded coalesced, x gathered in parallel, (val, x) parked in a
-// wave-private LDS strip, and the chain runs over the strip in CRS order — the same operations in the same
-// order as the reference, whatever the row length; the level's long rows run side by side.
-constexpr int SWEEP_CHUNK = 4 * ITS_WAVE;   // entries of a long row staged per trip (4 per lane)
+// Short rows (<= SWEEP_SHORT entries, listed first) take one lane each, gathers eight at a time
+// (sweep_short_kernel).  Every longer row gets a whole wave (sweep_long_kernel): SWEEP_CHUNK entries of
+// col/val are loaded coalesced, x gathered in parallel, (val, x) parked in a wave-private LDS strip, and the
+// chain runs over the strip in CRS order — the same operations in the same order as the reference, whatever
+// the row length; the level's long rows run side by side.
+constexpr int SWEEP_LPL = 8;                        // entries of a long row per lane per chunk
+constexpr int SWEEP_CHUNK = SWEEP_LPL * ITS_WAVE;   // entries of a long row staged per trip
 
-__global__ __launch_bounds__(ITS_BLOCK) void sweep_level_kernel(
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_short_kernel(
     const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
-    const int *__restrict__ rows, int n_level_rows, int n_short, int short_blocks, double *x,
-    const double *__restrict__ rhs, const double *__restrict__ D)
+    const int *__restrict__ rows, int n_short, double *x, const double *__restrict__ rhs, const double *__restrict__ D)
 {
-    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][SWEEP_CHUNK];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if ((int)blockIdx.x < short_blocks) {
-        const int64_t nth = (int64_t)short_blocks * ITS_BLOCK;
+    {
+        const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
         for (int64_t k = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x; k < n_short; k += nth) {
             const int row = rows ? rows[k] : (int)k;
             const int j0 = rp[row], j1 = rp[row + 1];
@@ -1410,41 +1414,77 @@ __global__ __launch_bounds__(ITS_BLOCK) void sweep_level_kernel(
             }
             x[row] = (rhs[row] - s) / D[row];
         }
-        return;
     }
-    const int64_t wstride = (int64_t)(gridDim.x - short_blocks) * (ITS_BLOCK / ITS_WAVE);
-    for (int64_t k = n_short + (int64_t)(blockIdx.x - short_blocks) * (ITS_BLOCK / ITS_WAVE) + w; k < n_level_rows; k += wstride) {
-        const int row = rows ? rows[k] : (int)k;
+}
+
+// (a kernel of its own: its staging registers would halve the occupancy of the latency-bound short rows)
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_long_kernel(
+    const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+    const int *__restrict__ rows, int n_level_rows, int n_short, double *x,
+    const double *__restrict__ rhs, const double *__restrict__ D)
+{
+    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][SWEEP_CHUNK + 8];   // + 8: the chain reads one batch ahead
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    // Long rows.  The chain is serial by definition (one fused multiply-add per entry, in CRS order), so the
+    // level cannot finish before its longest row has walked its entries: everything else is kept off that path.
+    //   loads    two chunks ahead: col/val of chunk c+2 and the x gathers of chunk c+1 (whose columns arrived a
+    //            trip ago) are in flight while chunk c is walked, so no trip waits for a memory round trip
+    //   chain    reads LDS one batch of 8 ahead of the multiply-adds
+    const int64_t wstride = (int64_t)gridDim.x * (ITS_BLOCK / ITS_WAVE);
+    for (int64_t k = n_short + (int64_t)blockIdx.x * (ITS_BLOCK / ITS_WAVE) + w; k < n_level_rows; k += wstride) {
+        const int row = rows[k];
         const int rj0 = rp[row], rj1 = rp[row + 1];
         double acc = 0.0;
-        // chunk in flight: (val, x[col]) of entries c0 + l + 64 u, u = 0..3
-        double vv[4], xg[4];
-#define SWEEP_LOAD(c0v)                                                                   \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                   \
+        int cn[SWEEP_LPL];                    // columns of the chunk after next
+        double vn[SWEEP_LPL];                 // its values
+        double vv[SWEEP_LPL], xg[SWEEP_LPL];  // (val, x[col]) of the next chunk
+        // entry e of a chunk starting at c0 sits in lane (e - c0) % 64, slot (e - c0) / 64
+#define SWEEP_LOAD_CV(c0v)                                                                \
+        _Pragma("unroll") for (int u = 0; u < SWEEP_LPL; ++u) {                           \
             const int e_ = (c0v) + l + ITS_WAVE * u;                                      \
-            const int cc_ = e_ < rj1 ? col[e_] : 0;                                       \
-            vv[u] = e_ < rj1 ? val[e_] : 0.0;                                             \
-            xg[u] = x[cc_];                                                               \
+            cn[u] = e_ < rj1 ? col[e_] : 0;                                               \
+            vn[u] = e_ < rj1 ? val[e_] : 0.0;                                             \
         }
-        SWEEP_LOAD(rj0)
+#define SWEEP_GATHER()                                                                    \
+        _Pragma("unroll") for (int u = 0; u < SWEEP_LPL; ++u) { vv[u] = vn[u]; xg[u] = x[cn[u]]; }
+        SWEEP_LOAD_CV(rj0)
+        SWEEP_GATHER()
+        SWEEP_LOAD_CV(rj0 + SWEEP_CHUNK)
         for (int c0 = rj0; c0 < rj1; c0 += SWEEP_CHUNK) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s_vx[w][l + ITS_WAVE * u] = make_double2(vv[u], xg[u]);
-            SWEEP_LOAD(c0 + SWEEP_CHUNK)                  // next chunk goes out before the chain runs
+            for (int u = 0; u < SWEEP_LPL; ++u) s_vx[w][l + ITS_WAVE * u] = make_double2(vv[u], xg[u]);
+            SWEEP_GATHER()                                  // chunk c+1: its columns were loaded a trip ago
+            SWEEP_LOAD_CV(c0 + 2 * SWEEP_CHUNK)             // chunk c+2
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const int ne = min(SWEEP_CHUNK, rj1 - c0);
-            int q = 0;
-            for (; q + 8 <= ne; q += 8) {
-                double2 p[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) p[u] = s_vx[w][q + u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc = fma(p[u].x, p[u].y, acc);
+            {
+                // two register sets, no copies: the LDS reads of one set are in flight while the other is consumed
+                double2 pa[8], pb[8];
+#define SWEEP_RD(S, qv) _Pragma("unroll") for (int u = 0; u < 8; ++u) S[u] = s_vx[w][(qv) + u];
+#define SWEEP_FMA(S, cnt) _Pragma("unroll") for (int u = 0; u < 8; ++u) if (u < (cnt)) acc = fma(S[u].x, S[u].y, acc);
+                int q = 0;
+                SWEEP_RD(pa, 0)
+                for (; q + 16 <= ne; q += 16) {
+                    SWEEP_RD(pb, q + 8)
+                    SWEEP_FMA(pa, 8)
+                    SWEEP_RD(pa, q + 16)
+                    SWEEP_FMA(pb, 8)
+                }
+                if (q + 8 <= ne) {
+                    SWEEP_RD(pb, q + 8)
+                    SWEEP_FMA(pa, 8)
+                    q += 8;
+                    SWEEP_FMA(pb, ne - q)
+                } else {
+                    SWEEP_FMA(pa, ne - q)
+                }
+#undef SWEEP_RD
+#undef SWEEP_FMA
             }
-            for (; q < ne; ++q) { const double2 p1 = s_vx[w][q]; acc = fma(p1.x, p1.y, acc); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-#undef SWEEP_LOAD
+#undef SWEEP_LOAD_CV
+#undef SWEEP_GATHER
         if (l == 0) x[row] = (rhs[row] - acc) / D[row];
     }
 }
@@ -1459,8 +1499,12 @@ void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int 
     const int n_long = n_level_rows - n_short;
     int gl = (n_long + 3) / 4;
     if (gl > 4 * ITS_NPART) gl = 4 * ITS_NPART;
-    hipLaunchKernelGGL(sweep_level_kernel, dim3(gs + gl), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val,
-                       rows, n_level_rows, n_short, gs, x, rhs, D);
+    // rows of a level are independent, so the order of the two launches does not matter
+    if (gs > 0)
+        hipLaunchKernelGGL(sweep_short_kernel, dim3(gs), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val, rows, n_short, x, rhs, D);
+    if (gl > 0)
+        hipLaunchKernelGGL(sweep_long_kernel, dim3(gl), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val, rows, n_level_rows,
+                           n_short, x, rhs, D);
 }
 
 }  // namespace its

@@ -12,8 +12,9 @@ rp, col, val = matgen.laplace3d_7pt(N)
 n = len(rp) - 1
 for name in sys.argv[1:] or ["jacobi"]:
     orders = (capi.GS_LEVEL, capi.GS_MULTICOLOR) if name == "gauss-seidel" else (0,)
+    if os.environ.get("ORDER"): orders = (int(os.environ["ORDER"]),)
     for order in orders:
-        for fused in (1, 0):
+        for fused in ((1, 0) if not os.environ.get("FUSED") else (int(os.environ["FUSED"]),)):
             args = S.Args(name, S.LoopParams(max_iters=10**9, tol=0.0))
             sol = S.Solver(name, device=0, jacobi_mode=capi.JACOBI_REF, gs_order=order)
             sol.handle.set_option("fused_residual", fused)
