@@ -72,6 +72,11 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                      J, Q <- J Q, R = Q H, g = Q beta e1, methods/gmres.hpp:427-658): O(m^3) host
  *                      work per trip, reproduces the reference's |g[k+1]| also BELOW the attainable
  *                      accuracy, where the rotation form keeps shrinking and the dense form stalls.
+ *   "fused_residual" 1 (default) = a Jacobi / Gauss-Seidel trip reads A once: the pass that records
+ *                  ||b - A x_new|| (utility_funcs.hpp:423-447) also produces the next trip's product of
+ *                  x_new (second in-order chain per row); 0 = separate launches.  Same bits either way.
+ *   "sweep_stream" 1 (default) = sweep levels that are contiguous row ranges (the colours of a multicolour
+ *                  ordering) run on the exact SpMV kernels; 0 = level-list kernels only.  Same bits.
  * Process-wide launch options of the exact SpMV (any time; all lossless, results bit-identical):
  *   "spmv_idx"     1 (default) = stream the 1-byte column-offset dictionary index instead of the 4-byte
  *                  column when the matrix has <= 256 distinct col - row; 0 = always the plain col stream
@@ -125,7 +130,8 @@ int its_synchronize(its_handle *h);
  * events on the handle's own stream */
 /* with_dot == 1 launches the variant the CG loop uses (y = A x fused with the partial sums
  * of y.x, methods/cg.hpp:128,160) so its duration matches the in-loop kernel; 2 and 3 time the residual
- * epilogue (r = x - A x, with x standing in for b) with r stored (2) and norm-only (3). */
+ * epilogue (r = x - A x, with x standing in for b) with r stored (2) and norm-only (3); 4..7 time the
+ * Jacobi sweep, the GS right-hand side and their fused forms (sweep / rhs + recorded residual) the same way. */
 int its_spmv_timed(its_handle *h, int which, const double *x_dev, double *y_dev, int format,
                    int with_dot, int reps, float *avg_ms);
 int its_last_region_ms(its_handle *h, float *ms);
