@@ -14,7 +14,7 @@
 
 static void free_csr(CsrDev &A)
 {
-    dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc);
+    dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc); dfree(A.blk_desc_big);
     dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict); dfree(A.vidx); dfree(A.val_dict);
     A = CsrDev();
 }
@@ -257,6 +257,21 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     }
     if (dalloc(h, &A.blk_desc, desc.size())) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.blk_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
+    int longest_row = 0;
+    for (int i = 0; i < n_rows; ++i) longest_row = std::max(longest_row, row_ptr[i + 1] - row_ptr[i]);
+    if (longest_row <= 8 && n_rows > 0) {
+        // rows this short may run on spmv_stream4_kernel, which takes larger row blocks (its_kernels.h)
+        build_stream_plan(n_rows, row_ptr, blk, ITS_BLOCK, SPMV_NNZ_BIG);
+        A.n_blocks_big = (int)blk.size() - 1;
+        desc.assign(std::max(A.n_blocks_big, 1), make_int4(0, 0, 0, 0));
+        for (int i = 0; i < A.n_blocks_big; ++i) {
+            int longest = 0;
+            for (int r = blk[i]; r < blk[i + 1]; ++r) longest = std::max(longest, row_ptr[r + 1] - row_ptr[r]);
+            desc[i] = make_int4(blk[i], (blk[i + 1] - blk[i]) | (longest << 16), row_ptr[blk[i]], row_ptr[blk[i + 1]]);
+        }
+        if (dalloc(h, &A.blk_desc_big, desc.size())) return ITS_EHIP;
+        HIPCHK(h, hipMemcpy(A.blk_desc_big, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
     A.lanes_per_row = pick_lanes_per_row(n_rows, nnz);
     A.max_row_len = 0;
     for (int i = 0; i < n_rows; ++i) A.max_row_len = std::max(A.max_row_len, row_ptr[i + 1] - row_ptr[i]);

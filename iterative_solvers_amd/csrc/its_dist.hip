@@ -37,6 +37,9 @@ struct DistPlan {
     // row blocks without / with halo columns
     int4 *desc_int = nullptr, *desc_bnd = nullptr;
     int nb_int = 0, nb_bnd = 0;
+    // the same split of the larger-block plan (CsrDev::blk_desc_big), for launches that take it
+    int4 *desc_int_big = nullptr, *desc_bnd_big = nullptr;
+    int nb_int_big = 0, nb_bnd_big = 0;
 };
 
 #define NCCLCHK(h, call)                                                                   \
@@ -67,6 +70,7 @@ void its_dist_destroy(its_handle *h)
     if (d->ev_pack) (void)hipEventDestroy(d->ev_pack);
     if (d->ev_halo) (void)hipEventDestroy(d->ev_halo);
     dfree(d->send_idx); dfree(d->send_buf); dfree(d->desc_int); dfree(d->desc_bnd);
+    dfree(d->desc_int_big); dfree(d->desc_bnd_big);
     if (d->host_send) (void)hipHostFree(d->host_send);
     if (d->host_recv) (void)hipHostFree(d->host_recv);
     if (d->host_sc) (void)hipHostFree(d->host_sc);
@@ -166,23 +170,31 @@ extern "C" int its_dist_setup(its_handle *h, int n_nbr, const int *nbr, const in
         HIPCHK(h, hipHostMalloc((void **)&d->host_send, std::max(d->n_send, 1) * sizeof(double), hipHostMallocDefault));
         HIPCHK(h, hipHostMalloc((void **)&d->host_recv, std::max(n_halo, 1) * sizeof(double), hipHostMallocDefault));
     }
-    // split the row blocks of the stream plan: a block is "boundary" if any of its rows has a
+    // split the row blocks of the stream plan(s): a block is "boundary" if any of its rows has a
     // halo column (>= n_loc); interior blocks can be multiplied while the halo is in flight
-    std::vector<int4> desc(std::max(A.n_blocks, 1));
-    if (A.n_blocks) HIPCHK(h, hipMemcpy(desc.data(), A.blk_desc, (size_t)A.n_blocks * sizeof(int4), hipMemcpyDeviceToHost));
     std::vector<int> col((size_t)A.nnz);
     if (A.nnz) HIPCHK(h, hipMemcpy(col.data(), A.col, (size_t)A.nnz * sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<int4> di, db;
-    for (int b = 0; b < A.n_blocks; ++b) {
-        bool bnd = false;
-        for (int k = desc[b].z; k < desc[b].w && !bnd; ++k) bnd = col[k] >= n_loc;
-        (bnd ? db : di).push_back(desc[b]);
-    }
-    d->nb_int = (int)di.size(); d->nb_bnd = (int)db.size();
-    dfree(d->desc_int); dfree(d->desc_bnd);
-    if (dalloc(h, &d->desc_int, di.size()) || dalloc(h, &d->desc_bnd, db.size())) return ITS_EHIP;
-    if (!di.empty()) HIPCHK(h, hipMemcpy(d->desc_int, di.data(), di.size() * sizeof(int4), hipMemcpyHostToDevice));
-    if (!db.empty()) HIPCHK(h, hipMemcpy(d->desc_bnd, db.data(), db.size() * sizeof(int4), hipMemcpyHostToDevice));
+    auto split_plan = [&](const int4 *dev_desc, int nb, int4 **out_int, int *n_int, int4 **out_bnd, int *n_bnd) -> int {
+        std::vector<int4> desc(std::max(nb, 1));
+        if (nb) HIPCHK(h, hipMemcpy(desc.data(), dev_desc, (size_t)nb * sizeof(int4), hipMemcpyDeviceToHost));
+        std::vector<int4> di, db;
+        for (int b = 0; b < nb; ++b) {
+            bool bnd = false;
+            for (int k = desc[b].z; k < desc[b].w && !bnd; ++k) bnd = col[k] >= n_loc;
+            (bnd ? db : di).push_back(desc[b]);
+        }
+        *n_int = (int)di.size(); *n_bnd = (int)db.size();
+        dfree(*out_int); dfree(*out_bnd);
+        if (dalloc(h, out_int, di.size()) || dalloc(h, out_bnd, db.size())) return ITS_EHIP;
+        if (!di.empty()) HIPCHK(h, hipMemcpy(*out_int, di.data(), di.size() * sizeof(int4), hipMemcpyHostToDevice));
+        if (!db.empty()) HIPCHK(h, hipMemcpy(*out_bnd, db.data(), db.size() * sizeof(int4), hipMemcpyHostToDevice));
+        return ITS_OK;
+    };
+    int rcs = split_plan(A.blk_desc, A.n_blocks, &d->desc_int, &d->nb_int, &d->desc_bnd, &d->nb_bnd);
+    if (rcs) return rcs;
+    d->nb_int_big = d->nb_bnd_big = 0;
+    if (A.blk_desc_big && (rcs = split_plan(A.blk_desc_big, A.n_blocks_big, &d->desc_int_big, &d->nb_int_big, &d->desc_bnd_big, &d->nb_bnd_big)))
+        return rcs;
     d->plan_ready = true;
     h->setup_done = false; h->residual_done = false;
     return ITS_OK;
@@ -201,6 +213,9 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
         HIPCHK(h, hipGetLastError());
     }
     const bool split = h->fmt == ITS_FMT_CSR_EXACT || epi >= EPI_JACOBI_SHIPPED;
+    const bool big = split && spmv_exact_takes_big_plan(A, a, epi);
+    const int4 *desc_int = big ? d->desc_int_big : d->desc_int, *desc_bnd = big ? d->desc_bnd_big : d->desc_bnd;
+    const int nb_int = big ? d->nb_int_big : d->nb_int, nb_bnd = big ? d->nb_bnd_big : d->nb_bnd;
     if (d->transport == 1) {
         if (d->n_nbr) {
             HIPCHK(h, hipEventRecord(d->ev_pack, h->stream));
@@ -215,9 +230,9 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
             HIPCHK(h, hipEventRecord(d->ev_halo, d->cstream));
         }
         if (split) {
-            launch_spmv_exact_desc(A, d->desc_int, d->nb_int, a, epi, 0, h->stream);
+            launch_spmv_exact_desc(A, desc_int, nb_int, a, epi, 0, h->stream);
             if (d->n_nbr) HIPCHK(h, hipStreamWaitEvent(h->stream, d->ev_halo, 0));
-            if (d->nb_bnd) launch_spmv_exact_desc(A, d->desc_bnd, d->nb_bnd, a, epi, 1, h->stream);
+            if (nb_bnd) launch_spmv_exact_desc(A, desc_bnd, nb_bnd, a, epi, 1, h->stream);
         } else {
             if (d->n_nbr) HIPCHK(h, hipStreamWaitEvent(h->stream, d->ev_halo, 0));
             if (h->fmt == ITS_FMT_CSR_VECTOR) launch_spmv_vector(A, a, epi, h->stream);
@@ -226,13 +241,13 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
     } else {
         // HOST transport (tests): stage through the callbacks; interior blocks are still launched
         // first so the launch sequence matches production
-        if (split) launch_spmv_exact_desc(A, d->desc_int, d->nb_int, a, epi, 0, h->stream);
+        if (split) launch_spmv_exact_desc(A, desc_int, nb_int, a, epi, 0, h->stream);
         if (d->n_send) HIPCHK(h, hipMemcpyAsync(d->host_send, d->send_buf, (size_t)d->n_send * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (d->xcb(d->user, d->host_send, d->send_off.data(), d->host_recv, d->recv_off.data(), d->nbr.data(), d->n_nbr) != 0)
             FAIL(h, ITS_ECOMM, "host exchange callback failed");
         if (d->n_halo) HIPCHK(h, hipMemcpyAsync(x + n_loc, d->host_recv, (size_t)d->n_halo * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        if (split) { if (d->nb_bnd) launch_spmv_exact_desc(A, d->desc_bnd, d->nb_bnd, a, epi, 1, h->stream); }
+        if (split) { if (nb_bnd) launch_spmv_exact_desc(A, desc_bnd, nb_bnd, a, epi, 1, h->stream); }
         else if (h->fmt == ITS_FMT_CSR_VECTOR) launch_spmv_vector(A, a, epi, h->stream);
         else launch_spmv_sell(A, a, epi, h->stream);
     }

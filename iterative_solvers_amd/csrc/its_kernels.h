@@ -13,6 +13,10 @@ namespace its {
 // several LDS chunks).  blk_desc[nb] = {first row, rows | longest row << 16, first nnz, end nnz}.
 // ---------------------------------------------------------------------------------------
 constexpr int SPMV_NNZ_MAX = 1536;        // (1536+8)*(8+4) B + row ptrs ≈ 19.6 KB LDS per buffer
+// second plan for the two-workgroups-per-CU kernel of the CG form (spmv_stream4_kernel): the staging registers
+// hold 2048 entries per trip, and with 256 full rows per block (7-pt: 1792 entries) it runs 3 % faster; the
+// four-per-CU kernel needs the smaller LDS footprint of SPMV_NNZ_MAX
+constexpr int SPMV_NNZ_BIG = 2040;
 constexpr int IRR_ROW_LEN = 32;           // longest row above which the exact SpMV splits gather and arithmetic
 // col/val are allocated with this many zero elements after nnz: the stream kernel's prefetch
 // loads are unconditional (2 slices x 1024 entries past an aligned block start)
@@ -52,6 +56,8 @@ struct CsrDev {
     // stream plan
     int n_blocks = 0;
     int4 *blk_desc = nullptr;                 // {first row, rows, first nnz, end nnz} per row block
+    int n_blocks_big = 0;
+    int4 *blk_desc_big = nullptr;             // same with blocks of up to SPMV_NNZ_BIG entries (rows <= 8 entries only)
     // vector-CSR plan
     int lanes_per_row = 0;
     int max_row_len = 0;                      // longest row: > IRR_ROW_LEN selects the irregular-row exact kernel
@@ -85,6 +91,9 @@ void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStre
 int spmv_tune(const char *name, int value);
 void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const SpmvArgs &a, int epilogue,
                             int accumulate, hipStream_t s);
+// true when this launch would walk CsrDev::blk_desc_big (callers that pass descriptor lists of their own must
+// derive them from the matching plan: only spmv_stream4_kernel has room for the larger blocks)
+bool spmv_exact_takes_big_plan(const CsrDev &A, const SpmvArgs &a, int epilogue);
 void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 

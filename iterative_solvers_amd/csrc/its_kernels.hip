@@ -335,8 +335,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
 {
     constexpr bool IDX = CMP >= 1, VD = CMP == 2;
     __shared__ double s_vdict[VD ? 256 : 1];
-    __shared__ __attribute__((aligned(16))) double s_val[2][S2_CAP];
-    __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];    // IDX: col - row, decoded at commit
+    constexpr int S4_CAP = SPMV_NNZ_BIG + 8;
+    static_assert(SPMV_NNZ_BIG + 3 <= 2 * 4 * ITS_BLOCK, "staging is written for two slices of 4 entries per lane");
+    __shared__ __attribute__((aligned(16))) double s_val[2][S4_CAP];
+    __shared__ __attribute__((aligned(16))) int s_col[2][S4_CAP];    // IDX: col - row, decoded at commit
     __shared__ int s_rp[2][ITS_BLOCK + 4];
     __shared__ int s_dict[IDX ? 256 : 1];
     __shared__ double s_red[4];
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         const int4 dD = S4_DESC(it + 3);                                                                  \
         const int nr = d.y & 0xffff, nbat = (((d.y >> 16) + 7) >> 3);                                     \
         const int row = d.x + t;                                                                          \
-        const bool lng = d.w - d.z > SPMV_NNZ_MAX;                                                        \
+        const bool lng = d.w - d.z > SPMV_NNZ_BIG;                                                        \
         if (!lng) S4_COMMIT(R, d, buf);                                                                   \
         __syncthreads();                                                                                  \
         if (pend_row >= 0) { a.y[pend_row] = pend_val; pend_row = -1; }                                   \
@@ -446,8 +448,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         } else {                                                                                          \
             /* one row longer than the LDS capacity: stream it through the buffer in chunks, lane 0 */    \
             /* keeps the in-order chain (rare: power-law tails) */                                        \
-            for (int c0 = d.z; c0 < d.w; c0 += SPMV_NNZ_MAX) {                                            \
-                const int c1 = min(d.w, c0 + SPMV_NNZ_MAX);                                               \
+            for (int c0 = d.z; c0 < d.w; c0 += SPMV_NNZ_BIG) {                                            \
+                const int c1 = min(d.w, c0 + SPMV_NNZ_BIG);                                               \
                 const int base = c0 & ~3;                                                                 \
                 __syncthreads();                                                                          \
                 for (int i = base + 4 * t; i < c1; i += 4 * ITS_BLOCK) {                                  \
@@ -839,6 +841,7 @@ static int g_spmv_irr = env_int("ITS_SPMV_IRR", 1);             // 0 = never use
 static int g_spmv_irr_grid = env_int("ITS_SPMV_IRR_GRID", 1280);
 static int g_spmv_irr_len = env_int("ITS_SPMV_IRR_LEN", IRR_ROW_LEN);   // longest row above which it is used
 static int g_spmv_nt = env_int("ITS_SPMV_NT", 0);
+static int g_spmv_bigplan = env_int("ITS_SPMV_BIGPLAN", 1);     // 0 = spmv_stream4_kernel on the ordinary plan too
 int spmv_tune(const char *name, int value)
 {
     if (!strcmp(name, "spmv_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_grid = value; return 0; }
@@ -849,6 +852,7 @@ int spmv_tune(const char *name, int value)
     if (!strcmp(name, "spmv_irr")) { if (value < 0 || value > 1) return -1; g_spmv_irr = value; return 0; }
     if (!strcmp(name, "spmv_irr_len")) { if (value < 1) return -1; g_spmv_irr_len = value; return 0; }
     if (!strcmp(name, "spmv_irr_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_irr_grid = value; return 0; }
+    if (!strcmp(name, "spmv_bigplan")) { if (value < 0 || value > 1) return -1; g_spmv_bigplan = value; return 0; }
     if (!strcmp(name, "spmv_nt")) { if (value < 0 || value > 3) return -1; g_spmv_nt = value; return 0; }
     return -2;
 }
@@ -948,9 +952,18 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
 #undef ITS_LAUNCH2
 }
 
+// the CG form on spmv_stream4_kernel walks the plan with the larger row blocks (same test as the dispatch above)
+bool spmv_exact_takes_big_plan(const CsrDev &A, const SpmvArgs &a, int epi)
+{
+    return g_spmv_bigplan && A.blk_desc_big && g_spmv_variant == 4 && A.max_row_len <= 8 && epi == EPI_STORE && a.dotv &&
+           !(A.max_row_len > g_spmv_irr_len && g_spmv_irr) &&
+           !(A.n_off > 0 && g_spmv_idx && A.n_vals > 0 && g_spmv_valdict);
+}
+
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
 {
-    launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s);
+    if (spmv_exact_takes_big_plan(A, a_in, epi)) launch_spmv_exact_desc(A, A.blk_desc_big, A.n_blocks_big, a_in, epi, 0, s);
+    else launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s);
 }
 
 // ======================================================================================
