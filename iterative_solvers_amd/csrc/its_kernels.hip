@@ -129,16 +129,25 @@ __device__ __forceinline__ double row_finish(double acc, double acc2, double dia
     return outv;
 }
 
-// IDX: stream the 1-byte column-offset dictionary index instead of col (see spmv_stream4_kernel, CMP = 1)
-template <int EPI, bool DOT, bool IDX>
+// IDX != 0: stream the 1-byte column-offset dictionary index instead of col (see spmv_stream4_kernel, CMP = 1)
+//   1  decoded to col - row when the block is committed to LDS (4 bytes per entry there)
+//   2  kept as a byte in LDS and decoded in the walk: room for the larger row blocks at four workgroups per CU.
+//      Chosen for rows of <= 8 entries (7-pt: plain SpMV 0.304 -> 0.292 ms); for 27-entry rows the second
+//      dependent LDS read per entry costs more than it saves (GMRES trip 0.542 -> 0.566 ms), they keep 1
+template <int EPI, bool DOT, int IDX>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
     int nb, const int4 *__restrict__ blk_desc, const int *__restrict__ rp,
     const int *__restrict__ col, const double *__restrict__ val, int n_rows,
     const unsigned char *__restrict__ cidx, const int *__restrict__ off_dict, SpmvArgs a)
 {
     constexpr int NT = 0;
-    __shared__ __attribute__((aligned(16))) double s_val[2][S2_CAP];
-    __shared__ __attribute__((aligned(16))) int s_col[2][S2_CAP];    // IDX: col - row, decoded at commit
+    // IDX == 2: 9 instead of 12 bytes of LDS per entry, so four workgroups per CU still fit with blocks of up to
+    // SPMV_NNZ_BIG entries (full 256-row blocks for 7-pt)
+    constexpr int CAP = IDX == 2 ? SPMV_NNZ_BIG + 8 : S2_CAP;
+    constexpr int NNZ_CAP = IDX == 2 ? SPMV_NNZ_BIG : SPMV_NNZ_MAX;
+    __shared__ __attribute__((aligned(16))) double s_val[2][CAP];
+    __shared__ __attribute__((aligned(16))) int s_col[2][IDX == 2 ? 4 : CAP];    // IDX == 1: col - row
+    __shared__ __attribute__((aligned(16))) unsigned char s_idx[2][IDX == 2 ? CAP : 16];
     __shared__ int s_rp[2][ITS_BLOCK + 4];
     __shared__ int s_dict[IDX ? 256 : 1];
     __shared__ double s_red[4];
@@ -193,12 +202,14 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         const int base_ = (d).z & ~3;                                                     \
         const int oA_ = 4 * t, oB_ = oA_ + 4 * ITS_BLOCK;                                 \
         if (base_ + oA_ < (d).w) {                                                        \
-            *reinterpret_cast<int4 *>(&s_col[buf][oA_]) = IDX ? S2_DECODE(rcA.x) : rcA;   \
+            if (IDX == 2) *reinterpret_cast<int *>(&s_idx[buf][oA_]) = rcA.x;             \
+            else *reinterpret_cast<int4 *>(&s_col[buf][oA_]) = IDX ? S2_DECODE(rcA.x) : rcA; \
             *reinterpret_cast<double2 *>(&s_val[buf][oA_]) = rvA0;                        \
             *reinterpret_cast<double2 *>(&s_val[buf][oA_ + 2]) = rvA1;                    \
         }                                                                                 \
         if (base_ + oB_ < (d).w) {                                                        \
-            *reinterpret_cast<int4 *>(&s_col[buf][oB_]) = IDX ? S2_DECODE(rcB.x) : rcB;   \
+            if (IDX == 2) *reinterpret_cast<int *>(&s_idx[buf][oB_]) = rcB.x;             \
+            else *reinterpret_cast<int4 *>(&s_col[buf][oB_]) = IDX ? S2_DECODE(rcB.x) : rcB; \
             *reinterpret_cast<double2 *>(&s_val[buf][oB_]) = rvB0;                        \
             *reinterpret_cast<double2 *>(&s_val[buf][oB_ + 2]) = rvB1;                    \
         }                                                                                 \
@@ -219,7 +230,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         const int rs = d.x, nr = d.y;
         const int row = rs + t;
         double acc = 0.0, acc2 = 0.0, diag = 0.0;
-        const bool lng = d.w - d.z > SPMV_NNZ_MAX;
+        // (a matrix with a dictionary has no row longer than its 256 offsets: no long-row path under IDX)
+        const bool lng = !IDX && d.w - d.z > NNZ_CAP;
         if (!lng) {
             if (!have) S2_ISSUE(d);
             S2_COMMIT(d, cur);
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         __syncthreads();
         // the next block's col/val/row_ptr go out before the walk and stay in flight during it
         have = false;
-        if (it + 1 < niter && dn.w - dn.z <= SPMV_NNZ_MAX) { S2_ISSUE(dn); have = true; }
+        if (it + 1 < niter && (IDX || dn.w - dn.z <= NNZ_CAP)) { S2_ISSUE(dn); have = true; }
         if (!lng) {
             if (t < nr) {
                 const int base = d.z & ~3;
@@ -237,7 +249,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int jj = (j + u < j1) ? j + u : j;
-                        c[u] = IDX ? row + s_col[cur][jj] : s_col[cur][jj]; v[u] = s_val[cur][jj];
+                        c[u] = IDX == 2 ? row + s_dict[s_idx[cur][jj]] : (IDX ? row + s_col[cur][jj] : s_col[cur][jj]);
+                        v[u] = s_val[cur][jj];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];
@@ -249,8 +262,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         } else {
             // a single row longer than the LDS capacity: stream it through buffer `cur` in
             // chunks; lane 0 keeps the in-order chain.  (Rare: power-law tails.)
-            for (int c0 = d.z; c0 < d.w; c0 += SPMV_NNZ_MAX) {
-                const int c1 = min(d.w, c0 + SPMV_NNZ_MAX);
+            for (int c0 = d.z; c0 < d.w; c0 += NNZ_CAP) {
+                const int c1 = min(d.w, c0 + NNZ_CAP);
                 const int base = c0 & ~3;
                 __syncthreads();
                 for (int i = base + 4 * t; i < c1; i += 4 * ITS_BLOCK) {
@@ -870,11 +883,14 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
     a.part_accum = accumulate;
 #define ITS_LAUNCH2(E, D)                                                                                     \
     do {                                                                                                      \
-        if (A.n_off > 0 && g_spmv_idx)                                                                        \
-            hipLaunchKernelGGL((spmv_stream2_kernel<E, D, true>), dim3(g2v_long), b, 0, s, n_desc, desc, A.row_ptr, A.col, \
+        if (A.n_off > 0 && g_spmv_idx && A.blk_desc_big)                                                      \
+            hipLaunchKernelGGL((spmv_stream2_kernel<E, D, 2>), dim3(g2v_long), b, 0, s, n_desc, desc, A.row_ptr, A.col, \
+                               A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
+        else if (A.n_off > 0 && g_spmv_idx)                                                                   \
+            hipLaunchKernelGGL((spmv_stream2_kernel<E, D, 1>), dim3(g2v_long), b, 0, s, n_desc, desc, A.row_ptr, A.col, \
                                A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
         else                                                                                                  \
-            hipLaunchKernelGGL((spmv_stream2_kernel<E, D, false>), dim3(g2v_long), b, 0, s, n_desc, desc, A.row_ptr, A.col, \
+            hipLaunchKernelGGL((spmv_stream2_kernel<E, D, 0>), dim3(g2v_long), b, 0, s, n_desc, desc, A.row_ptr, A.col, \
                                A.val, A.n_rows, A.cidx, A.off_dict, a);                                       \
     } while (0)
     // irregular rows: the two-phase kernel (5 workgroups per CU by its LDS footprint)
@@ -955,9 +971,11 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
 // the CG form on spmv_stream4_kernel walks the plan with the larger row blocks (same test as the dispatch above)
 bool spmv_exact_takes_big_plan(const CsrDev &A, const SpmvArgs &a, int epi)
 {
-    return g_spmv_bigplan && A.blk_desc_big && g_spmv_variant == 4 && A.max_row_len <= 8 && epi == EPI_STORE && a.dotv &&
-           !(A.max_row_len > g_spmv_irr_len && g_spmv_irr) &&
-           !(A.n_off > 0 && g_spmv_idx && A.n_vals > 0 && g_spmv_valdict);
+    if (!g_spmv_bigplan || !A.blk_desc_big || (A.max_row_len > g_spmv_irr_len && g_spmv_irr) || g_spmv_variant == 5) return false;
+    const int cmp = (A.n_off > 0 && g_spmv_idx) ? ((A.n_vals > 0 && g_spmv_valdict) ? 2 : 1) : 0;
+    if (cmp == 2) return false;                                  // spmv_stream5_kernel: small LDS buffers
+    if (g_spmv_variant == 4 && A.max_row_len <= 8 && epi == EPI_STORE && a.dotv) return true;   // spmv_stream4_kernel
+    return cmp == 1;                                             // spmv_stream2_kernel<.., IDX = 2>
 }
 
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
