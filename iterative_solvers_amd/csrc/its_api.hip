@@ -275,10 +275,16 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     A.lanes_per_row = pick_lanes_per_row(n_rows, nnz);
     A.max_row_len = 0;
     for (int i = 0; i < n_rows; ++i) A.max_row_len = std::max(A.max_row_len, row_ptr[i + 1] - row_ptr[i]);
-    A.n_upper = 0;
-    if (which != ITS_MAT_L)                              // what trip_gs compares between A and crs_U
+    // what trip_gs compares between A and crs_U before it lets one pass over A stand in for the pass over U:
+    // count, column sum and an order-independent hash of the value bits of the entries right of the diagonal
+    A.n_upper = 0; A.upper_col_sum = 0; A.upper_val_xor = 0;
+    if (which != ITS_MAT_L)
         for (int i = 0; i < n_rows; ++i)
-            for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k) A.n_upper += col[k] > i;
+            for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+                if (col[k] > i) {
+                    uint64_t bits; memcpy(&bits, &val[k], 8);
+                    ++A.n_upper; A.upper_col_sum += col[k]; A.upper_val_xor ^= bits * 0x9E3779B97F4A7C15ull + (uint64_t)col[k];
+                }
     if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; }
     h->have[which] = true;
     if (which == ITS_MAT_A) { h->fmt = format; h->setup_done = false; h->residual_done = false; }
@@ -680,8 +686,10 @@ static int trip_gs(its_handle *h, double *res_out)
     // (not for matrices on the irregular-row kernel: its one-lane-per-row walk out of LDS is issue-bound, and the
     // per-entry column test of the second chain costs more there than the separate pass over U: 2.7 vs 2.3 ms on
     // the power-law matrix in multicolour order)
-    const bool fused = h->fused_residual && h->mat[ITS_MAT_U].nnz == h->mat[ITS_MAT_A].n_upper &&
-                       h->mat[ITS_MAT_A].max_row_len <= IRR_ROW_LEN;
+    const CsrDev &Am = h->mat[ITS_MAT_A], &Um = h->mat[ITS_MAT_U];
+    const bool fused = h->fused_residual && Um.nnz == Am.n_upper && Um.n_upper == Um.nnz &&
+                       Um.upper_col_sum == Am.upper_col_sum && Um.upper_val_xor == Am.upper_val_xor &&
+                       Am.max_row_len <= IRR_ROW_LEN;
     if (!(fused && h->ahead)) {
         if ((rc = spmv_dispatch(h, h->mat[ITS_MAT_U], u, EPI_GS_RHS, ITS_FMT_CSR_EXACT))) return rc;   // gauss_seidel.hpp:144,177
     }

@@ -62,6 +62,8 @@ struct CsrDev {
     int lanes_per_row = 0;
     int max_row_len = 0;                      // longest row: > IRR_ROW_LEN selects the irregular-row exact kernel
     int64_t n_upper = 0;                      // entries with col > row (what a matching crs_U must hold)
+    int64_t upper_col_sum = 0;                // their column sum and a hash of their values: crs_U is compared on all three
+    uint64_t upper_val_xor = 0;
     // SELL-64-sigma image
     int sell_chunks = 0, sell_sigma = 0;
     int64_t sell_elems = 0;

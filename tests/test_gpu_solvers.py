@@ -234,3 +234,28 @@ def test_multicolor_sweep_on_stream_kernels_is_bit_identical(gen):
     k = min(len(out[0][0]), len(ref["history"]))
     assert np.max(np.abs(out[0][0][:k] - ref["history"][:k])) <= 1e-10 * ref["r0_two"]
     assert ref["r0_two"] > 1.0
+
+
+def test_gs_fusion_is_refused_for_a_foreign_crs_U():
+    """The one-pass GS trip takes its b - U x from A's entries right of the diagonal, which is only the same
+    thing if crs_U is that part of A: count, column sum and value hash are compared, and a crs_U that differs
+    (one value doubled here) keeps the separate pass over U.  Both settings must then walk the same launches."""
+    rp, col, val = MATRICES["lap3d_8"]()
+    n = len(rp) - 1
+    (Lp, Lc, Lv), (Up, Uc, Uv) = S.split_L_U(n, rp, col, val)
+    Uv = Uv.copy(); Uv[5] *= 2.0
+    out = []
+    for fused in (1, 0):
+        h = capi.Handle(0)
+        try:
+            h.set_option("fused_residual", fused)
+            h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+            h.upload_crs(Lp, Lc, Lv, capi.MAT_L, capi.FMT_CSR_EXACT)
+            h.upload_crs(Up, Uc, Uv, capi.MAT_U, capi.FMT_CSR_EXACT)
+            h.upload_vectors(np.full(n, 6.0), np.ones(n), np.zeros(n))
+            h.init_residual()
+            h.solver_setup(capi.GAUSS_SEIDEL)
+            out.append([h.iterate(i) for i in range(12)])
+        finally:
+            h.close()
+    assert out[0] == out[1]
