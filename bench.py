@@ -116,7 +116,11 @@ def main():
     h = sol.handle
     # ITS_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL communicators, split SpMV, all-reduced
     # scalars) even at world = 1, to see what that path costs per trip without a second GPU
-    force_dist = os.environ.get("ITS_BENCH_FORCE_DIST", "0") == "1"
+    # ITS_BENCH_FORCE_DIST=2: the same, and the rank is its own z-neighbour on both sides (the middle slab of three
+    # with the outer two folded onto it), so the halo planes really travel through pack kernel -> RCCL send/recv ->
+    # boundary SpMV: the whole per-trip cost of the N > 1 path except the xGMI wire (never a reported number)
+    force_dist = os.environ.get("ITS_BENCH_FORCE_DIST", "0") in ("1", "2")
+    loopback = os.environ.get("ITS_BENCH_FORCE_DIST", "0") == "2"
     if world == 1 and not force_dist:
         rp, col, val = matgen.laplace3d_7pt(N)
         n = len(rp) - 1
@@ -125,14 +129,30 @@ def main():
         S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
     else:
         from iterative_solvers_amd import distributed as D
-        rp, colg, val = matgen.laplace3d_7pt_slab(N, rank * N, (rank + 1) * N, world * N)
+        if loopback and world == 1:
+            rp, colg, val = matgen.laplace3d_7pt_slab(N, N, 2 * N, 3 * N)
+        else:
+            rp, colg, val = matgen.laplace3d_7pt_slab(N, rank * N, (rank + 1) * N, world * N)
         n = len(rp) - 1
         nnz = len(colg)
         if host_transport:
             D.init_comm_host(h, rank, world, rdzv)
         else:
             D.init_comm(h, rank, world, rdzv)
-        D.upload_slab(h, rdzv, world * n, rank * n, rp, colg, val, fmt)
+        if loopback and world == 1:
+            import ctypes as C
+            P = N * N
+            colg = np.asarray(colg, dtype=np.int64)
+            coll = np.where(colg < n, n + (colg - (n - P)),                    # plane below -> halo [n, n+P)
+                            np.where(colg >= 2 * n, n + P + (colg - 2 * n),        # plane above -> halo [n+P, n+2P)
+                                     colg - n)).astype(np.int32)
+            h.upload_crs(rp, coll, val, capi.MAT_A, fmt, n_cols=n + 2 * P)
+            send_idx = np.concatenate([np.arange(n - P, n), np.arange(0, P)]).astype(np.int32)   # own top, own bottom
+            nbr = np.zeros(1, np.int32); off = np.array([0, 2 * P], np.int32)
+            h.check(h.L.its_dist_setup(h.h, 1, nbr.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                       send_idx.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p)), "its_dist_setup")
+        else:
+            D.upload_slab(h, rdzv, world * n, rank * n, rp, colg, val, fmt)
         diag = np.full(n, 6.0)
         h.upload_vectors(diag, np.ones(n), np.ones(n))
         h.init_residual()
@@ -208,7 +228,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"CG fp64, 3-D 7-pt Laplacian, {N}^3 rows per GPU (grid {N}x{N}x{N * world}), b=1, x0=1, -scale none",
                        "rows_per_gpu": n, "nnz_per_gpu": nnz, "spmv_format": a.format,
-                       "parallelism": (f"row-block z-slabs x{world}" + (" (HOST rehearsal transport, one GPU)" if host_transport else " over RCCL")) if world > 1 else "single GPU"},
+                       "parallelism": (f"row-block z-slabs x{world}" + (" (HOST rehearsal transport, one GPU)" if host_transport else " over RCCL")) if world > 1
+                                      else ("single GPU, RCCL loopback rehearsal of the N > 1 path" if loopback else "single GPU")},
             "cg_GBps_algorithmic": cg_iter_bytes(n, nnz) * its_per_s / 1e9,
             "cg_frac_of_hbm_peak": cg_iter_bytes(n, nnz) * its_per_s / 1e9 / HBM_PEAK_GBS,
             "async_loop_ms_per_step": async_ms,

@@ -29,6 +29,7 @@ extern "C" int its_create(its_handle **out, int device)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ITS_EHIP;
     its_handle *h = new its_handle;
+    if (const char *e = getenv("ITS_DIST_OVERLAP")) h->dist_overlap = atoi(e) != 0;
     if (device >= 0) { if (hipSetDevice(device) != hipSuccess) { delete h; return ITS_EHIP; } }
     (void)hipGetDevice(&h->device);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ITS_EHIP; }
@@ -308,6 +309,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "gmres_givens: 0 (rotations) or 1 (reference dense products)");
         if (h->setup_done && h->solver == ITS_GMRES) FAIL(h, ITS_ESTATE, "set gmres_givens before its_solver_setup");
         h->gmres_givens = value;
+        return ITS_OK;
+    }
+    if (!strcmp(name, "dist_overlap")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "dist_overlap: 0 or 1");
+        h->dist_overlap = value;
         return ITS_OK;
     }
     if (!strcmp(name, "sweep_stream")) {

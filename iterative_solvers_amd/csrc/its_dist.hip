@@ -156,7 +156,9 @@ extern "C" int its_dist_setup(its_handle *h, int n_nbr, const int *nbr, const in
     // validate what the pack kernel and the receives assume
     if (d->recv_off.back() != n_halo) FAIL(h, ITS_EINVAL, "recv_off must cover the halo exactly");
     for (int k = 0; k < n_nbr; ++k) {
-        if (nbr[k] < 0 || nbr[k] >= d->world || nbr[k] == d->rank) FAIL(h, ITS_EINVAL, "bad neighbour rank");
+        // (a rank is its own neighbour only in a one-rank world: a periodic problem whose wrap-around entries
+        // travel through the same send/recv path — how the RCCL exchange is exercised on a single GPU)
+        if (nbr[k] < 0 || nbr[k] >= d->world || (nbr[k] == d->rank && d->world > 1)) FAIL(h, ITS_EINVAL, "bad neighbour rank");
         if (d->send_off[k + 1] < d->send_off[k] || d->recv_off[k + 1] < d->recv_off[k]) FAIL(h, ITS_EINVAL, "offsets not monotone");
     }
     for (int i = 0; i < d->n_send; ++i)
@@ -216,7 +218,25 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
     const bool big = split && spmv_exact_takes_big_plan(A, a, epi);
     const int4 *desc_int = big ? d->desc_int_big : d->desc_int, *desc_bnd = big ? d->desc_bnd_big : d->desc_bnd;
     const int nb_int = big ? d->nb_int_big : d->nb_int, nb_bnd = big ? d->nb_bnd_big : d->nb_bnd;
-    if (d->transport == 1) {
+    if (d->transport == 1 && !h->dist_overlap) {
+        // Default: exchange first, on the compute stream, then ONE product over the ordinary plan.  Measured with
+        // the one-GPU loopback (bench.py, ITS_BENCH_FORCE_DIST=2): run beside the persistent SpMV grid, the RCCL
+        // send/recv kernel's workgroups spin for 100-330 us waiting for CUs and for each other and slow the
+        // product down to 415 us (trip 0.637 ms); run alone it takes 6-20 us (trip 0.53 ms).  Hiding a 20 us
+        // exchange is not worth a tenth of that.
+        if (d->n_nbr) {
+            NCCLCHK(h, ncclGroupStart());
+            for (int k = 0; k < d->n_nbr; ++k) {
+                const int ns = d->send_off[k + 1] - d->send_off[k], nr = d->recv_off[k + 1] - d->recv_off[k];
+                if (ns) NCCLCHK(h, ncclSend(d->send_buf + d->send_off[k], ns, ncclDouble, d->nbr[k], d->comm_halo, h->stream));
+                if (nr) NCCLCHK(h, ncclRecv(x + n_loc + d->recv_off[k], nr, ncclDouble, d->nbr[k], d->comm_halo, h->stream));
+            }
+            NCCLCHK(h, ncclGroupEnd());
+        }
+        if (split) launch_spmv_exact(A, a, epi, h->stream);
+        else if (h->fmt == ITS_FMT_CSR_VECTOR) launch_spmv_vector(A, a, epi, h->stream);
+        else launch_spmv_sell(A, a, epi, h->stream);
+    } else if (d->transport == 1) {
         if (d->n_nbr) {
             HIPCHK(h, hipEventRecord(d->ev_pack, h->stream));
             HIPCHK(h, hipStreamWaitEvent(d->cstream, d->ev_pack, 0));

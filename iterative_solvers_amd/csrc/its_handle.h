@@ -59,6 +59,7 @@ struct its_handle {
     // (Jacobi: the next iterate in x_b; GS: b - U x in tmp) is already there.  Option "fused_residual" = 0
     // keeps the two separate launches (same bits).
     int fused_residual = 1;
+    int dist_overlap = 0;                        // option "dist_overlap": halo exchange beside the interior SpMV (its_dist.hip)
     bool ahead = false;
     bool setup_done = false, residual_done = false;
     double last_residual = 0.0;

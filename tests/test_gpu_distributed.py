@@ -84,3 +84,70 @@ def test_rccl_world_one_matches_single_gpu():
     assert hists[0][0] == hists[1][0]
     assert hists[0][1] == hists[1][1]                      # bit-identical: same reduction tree
     assert np.array_equal(hists[0][2], hists[1][2])
+
+
+def _periodic_z_laplacian(N, diag=7.0):
+    """7-pt stencil on an N^3 grid, periodic in z (SPD with diag > 6): the global matrix and the one-rank local
+    form whose wrap-around columns are halo entries [n, n + 2 N^2): first the copy of plane N-1, then of plane 0."""
+    n = N * N * N
+    idx = np.arange(n).reshape(N, N, N)                      # [z, y, x]
+    rows, cols_g, cols_l, vals = [], [], [], []
+    P = N * N
+    for dz, dy, dx in ((-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0)):
+        z, y, x = np.meshgrid(np.arange(N), np.arange(N), np.arange(N), indexing="ij")
+        zz, yy, xx = z + dz, y + dy, x + dx
+        ok = (yy >= 0) & (yy < N) & (xx >= 0) & (xx < N)
+        wrap_lo, wrap_hi = zz < 0, zz >= N
+        zg = zz % N
+        g = idx[zg[ok], yy[ok], xx[ok]]
+        l = g.copy()
+        plane_pos = (yy * N + xx)[ok]
+        l[wrap_lo[ok]] = n + plane_pos[wrap_lo[ok]]          # copy of plane N-1
+        l[wrap_hi[ok]] = n + P + plane_pos[wrap_hi[ok]]      # copy of plane 0
+        rows.append(idx[ok]); cols_g.append(g); cols_l.append(l)
+        vals.append(np.full(g.size, diag if (dz, dy, dx) == (0, 0, 0) else -1.0))
+    rows = np.concatenate(rows); cg_ = np.concatenate(cols_g); cl_ = np.concatenate(cols_l); v = np.concatenate(vals)
+    def to_crs(c):
+        order = np.lexsort((c, rows))
+        rp = np.zeros(n + 1, dtype=np.int32); np.add.at(rp, rows + 1, 1); rp = np.cumsum(rp).astype(np.int32)
+        return rp, c[order].astype(np.int32), v[order]
+    send_idx = np.concatenate([idx[N - 1].ravel(), idx[0].ravel()]).astype(np.int32)
+    return n, to_crs(cg_), to_crs(cl_), send_idx
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_rccl_send_recv_loopback_on_one_gpu(overlap):
+    """The RCCL halo exchange (pack kernel -> grouped ncclSend/ncclRecv on the side stream -> boundary SpMV after
+    the halo event) run for real on ONE GPU: a one-rank world whose only neighbour is itself, carrying the
+    wrap-around planes of a z-periodic Laplacian.  Checked against the same system as one global matrix."""
+    import ctypes as C
+    N = 12
+    n, (rpg, colg, valg), (rpl, coll, vall), send_idx = _periodic_z_laplacian(N)
+    P = N * N
+    hists = []
+    for loop in (False, True):
+        h = capi.Handle(0)
+        try:
+            if loop:
+                h.set_option("dist_overlap", overlap)        # 0: exchange, then one product; 1: beside the interior product
+                ids = C.create_string_buffer(256)
+                h.check(h.L.its_comm_unique_id(ids), "its_comm_unique_id")
+                h.check(h.L.its_comm_unique_id(C.byref(ids, 128)), "its_comm_unique_id")
+                h.check(h.L.its_comm_init(h.h, 0, 1, ids), "its_comm_init")
+                h.upload_crs(rpl, coll, vall, n_cols=n + 2 * P)
+                nbr = np.zeros(1, np.int32); off = np.array([0, 2 * P], np.int32)
+                h.check(h.L.its_dist_setup(h.h, 1, nbr.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                           send_idx.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p)), "its_dist_setup")
+            else:
+                h.upload_crs(rpg, colg, valg)
+            h.upload_vectors(np.full(n, 7.0), np.ones(n), np.zeros(n))
+            r0 = h.init_residual()
+            h.solver_setup(capi.CG)
+            hist = [h.iterate(i) for i in range(25)]
+            hists.append((r0, hist, h.download_x(n, 25)))
+        finally:
+            h.close()
+    assert abs(hists[0][0][1] - hists[1][0][1]) <= 1e-13 * hists[0][0][1]
+    a, b = np.array(hists[0][1]), np.array(hists[1][1])
+    assert np.all(np.abs(a - b) <= 1e-11 * np.maximum(a, 1e-3 * a[0]))
+    assert np.max(np.abs(hists[0][2] - hists[1][2])) <= 1e-11 * np.max(np.abs(hists[0][2]))
