@@ -379,14 +379,21 @@ static int solver_spmv(its_handle *h, const SpmvArgs &a, int epi)
     return spmv_dispatch(h, h->mat[ITS_MAT_A], a, epi, h->fmt);
 }
 
-// partials -> one device scalar (all-reduced across ranks when distributed)
-static int finish_scalar(its_handle *h, const double *part, double *out, int mode)
+// Distributed reductions: the ITS_NPART partials of every rank are summed (or maxed) element-wise across ranks,
+// in place, by ONE all-reduce of 16 KB; whoever consumes them then re-sums the array exactly as on one GPU.  No
+// finalize launch and no scalar hand-off in front of the collective, the same code path behind it, and with one
+// rank the values are the single-GPU ones bit for bit.
+static int allreduce_partials(its_handle *h, double *part, int op)
 {
-    if (!its_dist_active(h)) { launch_reduce_finalize(part, out, mode, h->stream); return ITS_OK; }
-    launch_reduce_finalize(part, out, mode == FIN_MAX ? FIN_MAX : FIN_SUM, h->stream);
-    int rc = its_dist_allreduce(h, out, 1, mode == FIN_MAX ? 1 : 0);
+    return its_dist_active(h) ? its_dist_allreduce(h, part, ITS_NPART, op) : ITS_OK;
+}
+
+// partials -> one device scalar
+static int finish_scalar(its_handle *h, double *part, double *out, int mode)
+{
+    int rc = allreduce_partials(h, part, mode == FIN_MAX ? 1 : 0);
     if (rc) return rc;
-    if (mode == FIN_SQRT) launch_sqrt_scalar(out, out, h->stream);
+    launch_reduce_finalize(part, out, mode, h->stream);
     return ITS_OK;
 }
 
@@ -625,18 +632,10 @@ static int trip_cg(its_handle *h, double *res_out)
     int rc = solver_spmv(h, a, EPI_STORE);                            // cg.hpp:128,160
     if (rc) return rc;
     if (prof) { HIPCHK(h, hipEventRecord(h->prof_ev[2 * h->prof_n + 1], h->stream)); ++h->prof_n; }
-    const double *pq = h->part[0]; int pq_scalar = 0;
-    if (its_dist_active(h)) {
-        if ((rc = finish_scalar(h, h->part[0], h->sc + SC_PQ, FIN_SUM))) return rc;
-        pq = h->sc + SC_PQ; pq_scalar = 1;
-    }
-    launch_cg_update_r(h->r, h->tmp, n, pq, pq_scalar, rr_in, h->sc, h->part[1], h->stream);
-    const double *rr = h->part[1]; int rr_scalar = 0;
-    if (its_dist_active(h)) {
-        if ((rc = finish_scalar(h, h->part[1], h->sc + SC_TMP, FIN_SUM))) return rc;
-        rr = h->sc + SC_TMP; rr_scalar = 1;
-    }
-    launch_cg_update_xp(h->x_a, h->p, h->r, n, rr, rr_scalar, rr_in, rr_out, h->sc, res_out, h->stream);
+    if ((rc = allreduce_partials(h, h->part[0], 0))) return rc;       // p.Ap over all ranks
+    launch_cg_update_r(h->r, h->tmp, n, h->part[0], 0, rr_in, h->sc, h->part[1], h->stream);
+    if ((rc = allreduce_partials(h, h->part[1], 0))) return rc;       // r.r over all ranks
+    launch_cg_update_xp(h->x_a, h->p, h->r, n, h->part[1], 0, rr_in, rr_out, h->sc, res_out, h->stream);
     h->rr_slot ^= 1;
     HIPCHK(h, hipGetLastError());
     return ITS_OK;
@@ -723,7 +722,6 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     int rc = solver_spmv(h, a, EPI_STORE);                            // gmres.hpp:234
     if (rc) return rc;
     if (h->precond == ITS_PRECOND_GS) { if ((rc = sweep(h, w, w))) return rc; }   // gmres.hpp:251
-    const bool dist = its_dist_active(h);
     // MGS (gmres.hpp:269-329): step j finishes w -= h_{j-1} v_{j-1} and starts h_j = w . v_j
     const double *prev_part = nullptr; int prev_scalar = 0;
     for (int j = 0; j <= k + 1; ++j) {
@@ -733,11 +731,7 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
         launch_mgs_step(w, v_prev, prev_part, prev_scalar, v_next, next_part,
                         j > 0 ? h->hcol_dev + (j - 1) : nullptr, n, h->stream);
         prev_part = next_part; prev_scalar = 0;
-        if (dist) {
-            double *s = h->sc + SC_TMP + (j & 1);
-            if ((rc = finish_scalar(h, next_part, s, FIN_SUM))) return rc;
-            prev_part = s; prev_scalar = 1;
-        }
+        if ((rc = allreduce_partials(h, next_part, 0))) return rc;
     }
     // H[k+1,k] = ||w||, V[k+1] = w / H[k+1,k]   (gmres.hpp:359,389)
     launch_mgs_normalize(h->V + (size_t)(k + 1) * ld, w, prev_part, prev_scalar, h->hcol_dev + (k + 1), n, h->stream);
@@ -917,7 +911,7 @@ extern "C" int its_gmres_restart(its_handle *h, int iter_count)
     if ((rc = gmres_get_x(h, h->x, h->x_a, iter_count))) return rc;
     SpmvArgs a; a.x = h->x; a.y = h->r; a.b = h->b; a.part_sum = h->part[0];
     if ((rc = solver_spmv(h, a, EPI_RESIDUAL))) return rc;
-    const double *nrm_part = h->part[0];
+    double *nrm_part = h->part[0];
     if (h->precond == ITS_PRECOND_GS) {
         if ((rc = sweep(h, h->r, h->r))) return rc;
         launch_dot_partials(h->r, h->r, n, h->part[1], h->stream);

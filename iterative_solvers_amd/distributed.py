@@ -172,11 +172,9 @@ def init_comm_host(handle: capi.Handle, rank: int, world: int, rdzv) -> None:
 
     def allreduce(user, vals, count, op):
         try:
-            mine = np.array([vals[i] for i in range(count)])
-            parts = [np.frombuffer(b, dtype=np.float64) for b in rdzv.allgather_bytes(mine.tobytes())]
-            res = np.max(parts, axis=0) if op == 1 else np.sum(parts, axis=0)   # rank order: deterministic
-            for i in range(count):
-                vals[i] = res[i]
+            buf = np.ctypeslib.as_array(vals, (count,))
+            parts = [np.frombuffer(b, dtype=np.float64) for b in rdzv.allgather_bytes(buf.tobytes())]
+            buf[:] = np.max(parts, axis=0) if op == 1 else np.sum(parts, axis=0)   # rank order: deterministic
             return 0
         except Exception:  # noqa: BLE001
             import traceback; traceback.print_exc()
