@@ -51,6 +51,15 @@ __device__ __forceinline__ double block_max(double v, double *red)
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
+// One workgroup's partial of a reduction: slot blockIdx.x, and zeros in the slots a smaller-than-ITS_NPART grid
+// leaves unowned, so that consumers can always sum all ITS_NPART.  Call from EVERY thread of the workgroup (v is
+// taken from thread 0; the zero slots are shared out over the threads).
+__device__ __forceinline__ void store_partial(double *__restrict__ part, double v)
+{
+    if (threadIdx.x == 0) part[blockIdx.x] = v;
+    for (int z = blockIdx.x + gridDim.x * (1 + (int)threadIdx.x); z < ITS_NPART; z += gridDim.x * ITS_BLOCK) part[z] = 0.0;
+}
+
 // Fixed-order sum of the ITS_NPART partials a previous kernel wrote (kernel boundary makes
 // them visible).  Every workgroup gets the same bits.
 __device__ __forceinline__ double sum_partials(const double *__restrict__ part, double *red)

@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void dot_partials_kernel(
     }
     for (int64_t i = 2 * n2 + tid; i < n; i += nth) s0 = fma(a[i], b[i], s0);
     const double bs = block_sum(s0 + s1, s_red);
-    if (threadIdx.x == 0) part[blockIdx.x] = bs;
+    store_partial(part, bs);
 }
 
 __global__ __launch_bounds__(ITS_BLOCK) void absmax_partials_kernel(
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void absmax_partials_kernel(
     double m = 0.0;
     for (int64_t i = tid; i < n; i += nth) m = fmax(m, fabs(v[i]));
     const double bm = block_max(m, s_red);
-    if (threadIdx.x == 0) part[blockIdx.x] = bm;
+    store_partial(part, bm);
 }
 
 __global__ __launch_bounds__(ITS_BLOCK) void reduce_finalize_kernel(
@@ -1244,24 +1244,31 @@ __global__ __launch_bounds__(ITS_BLOCK) void fill_kernel(double *__restrict__ ou
     for (int64_t i = tid; i < n; i += nth) out[i] = v;
 }
 
-static inline dim3 vgrid() { return dim3(ITS_NPART); }
+// vector kernels: at least 4 elements per thread, at most ITS_NPART workgroups.  Every consumer of a reduction
+// re-sums all ITS_NPART partials in each of its workgroups, which costs 16 KB of L2 reads per workgroup: on small
+// systems that re-sum, not the vectors, is the kernel (64 K rows: 5 us per launch on the full grid)
+static inline dim3 vgrid(int64_t n)
+{
+    int64_t g = (n + 4 * ITS_BLOCK - 1) / (4 * ITS_BLOCK);
+    return dim3((unsigned)std::min<int64_t>(std::max<int64_t>(g, 8), ITS_NPART));
+}
 
 void launch_dot_partials(const double *a, const double *b, int64_t n, double *part, hipStream_t s)
-{ hipLaunchKernelGGL(dot_partials_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, a, b, n, part); }
+{ hipLaunchKernelGGL(dot_partials_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, a, b, n, part); }
 void launch_absmax_partials(const double *v, int64_t n, double *part, hipStream_t s)
-{ hipLaunchKernelGGL(absmax_partials_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, v, n, part); }
+{ hipLaunchKernelGGL(absmax_partials_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, v, n, part); }
 void launch_reduce_finalize(const double *part, double *out, int mode, hipStream_t s)
 { hipLaunchKernelGGL(reduce_finalize_kernel, dim3(1), dim3(ITS_BLOCK), 0, s, part, out, mode); }
 void launch_sqrt_scalar(const double *in, double *out, hipStream_t s)
 { hipLaunchKernelGGL(sqrt_scalar_kernel, dim3(1), dim3(1), 0, s, in, out); }
 void launch_axpby(double *out, const double *a, const double *b, int64_t n, double sc, hipStream_t s)
-{ hipLaunchKernelGGL(axpby_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, out, a, b, n, sc); }
+{ hipLaunchKernelGGL(axpby_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, out, a, b, n, sc); }
 void launch_scale(double *out, const double *v, double sc, int64_t n, hipStream_t s)
-{ hipLaunchKernelGGL(scale_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, out, v, sc, n); }
+{ hipLaunchKernelGGL(scale_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, out, v, sc, n); }
 void launch_copy(double *out, const double *v, int64_t n, hipStream_t s)
 { (void)hipMemcpyAsync(out, v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s); }
 void launch_fill(double *out, double v, int64_t n, hipStream_t s)
-{ hipLaunchKernelGGL(fill_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, out, v, n); }
+{ hipLaunchKernelGGL(fill_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, out, v, n); }
 
 // ======================================================================================
 // CG vector updates (methods/cg.hpp:204-230) with the reductions fused in.
@@ -1295,10 +1302,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void cg_update_r_kernel(
         s0 = fma(rv, rv, s0);
     }
     const double bs = block_sum(s0 + s1, s_red);
-    if (threadIdx.x == 0) {
-        part_rr[blockIdx.x] = bs;
-        if (blockIdx.x == 0) { sc[SC_PQ] = pq; sc[SC_ALPHA] = alpha; }
-    }
+    store_partial(part_rr, bs);
+    if (threadIdx.x == 0 && blockIdx.x == 0) { sc[SC_PQ] = pq; sc[SC_ALPHA] = alpha; }
 }
 
 // Pass 2: beta = rr_new / rr_old; x += alpha p (alpha from pass 1, sc[SC_ALPHA]); p = r + beta p.
@@ -1339,11 +1344,11 @@ __global__ __launch_bounds__(ITS_BLOCK) void cg_update_xp_kernel(
 
 void launch_cg_update_r(double *r, const double *q, int64_t n, const double *part_pq, int pq_is_scalar,
                         const double *rr_in, double *sc, double *part_rr, hipStream_t s)
-{ hipLaunchKernelGGL(cg_update_r_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, r, q, n, part_pq, pq_is_scalar, rr_in, sc, part_rr); }
+{ hipLaunchKernelGGL(cg_update_r_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, r, q, n, part_pq, pq_is_scalar, rr_in, sc, part_rr); }
 
 void launch_cg_update_xp(double *x, double *p, const double *r, int64_t n, const double *part_rr, int rr_is_scalar,
                          const double *rr_old, double *rr_new, double *sc, double *res_out, hipStream_t s)
-{ hipLaunchKernelGGL(cg_update_xp_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, x, p, r, n, part_rr, rr_is_scalar, rr_old, rr_new, sc, res_out); }
+{ hipLaunchKernelGGL(cg_update_xp_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, x, p, r, n, part_rr, rr_is_scalar, rr_old, rr_new, sc, res_out); }
 
 // ======================================================================================
 // GMRES: modified Gram-Schmidt as fused "finish previous axpy + start next dot" steps.
@@ -1365,10 +1370,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void mgs_step_kernel(
         s0 = fma(wi, v_next ? v_next[i] : wi, s0);                         // gmres.hpp:286 / :359
     }
     const double bs = block_sum(s0, s_red);
-    if (threadIdx.x == 0) {
-        part_next[blockIdx.x] = bs;
-        if (blockIdx.x == 0 && h_out && v_prev) h_out[0] = h;
-    }
+    store_partial(part_next, bs);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && h_out && v_prev) h_out[0] = h;
 }
 
 __global__ __launch_bounds__(ITS_BLOCK) void mgs_normalize_kernel(
@@ -1399,13 +1402,13 @@ __global__ __launch_bounds__(ITS_BLOCK) void gmres_update_x_kernel(
 
 void launch_mgs_step(double *w, const double *v_prev, const double *part_prev, int prev_is_scalar,
                      const double *v_next, double *part_next, double *h_out, int64_t n, hipStream_t s)
-{ hipLaunchKernelGGL(mgs_step_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, w, v_prev, part_prev, prev_is_scalar, v_next, part_next, h_out, n); }
+{ hipLaunchKernelGGL(mgs_step_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, w, v_prev, part_prev, prev_is_scalar, v_next, part_next, h_out, n); }
 void launch_mgs_normalize(double *v_out, const double *w, const double *part_ww, int ww_is_scalar,
                           double *h_out, int64_t n, hipStream_t s)
-{ hipLaunchKernelGGL(mgs_normalize_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, v_out, w, part_ww, ww_is_scalar, h_out, n); }
+{ hipLaunchKernelGGL(mgs_normalize_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, v_out, w, part_ww, ww_is_scalar, h_out, n); }
 void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t ldv, const double *y_dev,
                            int m, int64_t n, hipStream_t s)
-{ hipLaunchKernelGGL(gmres_update_x_kernel, vgrid(), dim3(ITS_BLOCK), 0, s, x, x0, V, ldv, y_dev, m, n); }
+{ hipLaunchKernelGGL(gmres_update_x_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, x, x0, V, ldv, y_dev, m, n); }
 
 // ======================================================================================
 // Triangular sweep, one dependency level (or colour) per launch: each listed row computes
