@@ -89,7 +89,8 @@ struct SpmvArgs {
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 // same kernel over an explicit list of row-block descriptors (interior / boundary split of the
 // multi-GPU path); accumulate != 0 adds to the partials an earlier launch left
-// launch tunables of the exact SpMV: "spmv_grid", "spmv_map", "spmv_nt"; 0 ok, -1 bad value, -2 unknown name
+// launch tunables of the exact SpMV ("spmv_grid", "spmv_map", "spmv_variant", "spmv_idx", "spmv_valdict", "spmv_irr",
+// "spmv_irr_len", "spmv_irr_grid", "spmv_bigplan"); 0 ok, -1 bad value, -2 unknown name
 int spmv_tune(const char *name, int value);
 void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const SpmvArgs &a, int epilogue,
                             int accumulate, hipStream_t s);

@@ -842,7 +842,7 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-// launch tunables of the exact SpMV (its_set_option "spmv_grid" / "spmv_map" / "spmv_nt")
+// launch tunables of the exact SpMV (its_set_option "spmv_grid" / "spmv_map" / ...)
 // defaults measured on MI355X, 256^3 7-pt: v4 with 2 workgroups per CU (0.369 ms) vs v2 with 4 (0.376 ms)
 static int g_spmv_variant = env_int("ITS_SPMV_VARIANT", 4);
 static int g_spmv_grid = env_int("ITS_SPMV_GRID", g_spmv_variant >= 4 ? 512 : 1024);
@@ -853,7 +853,6 @@ static int g_spmv_vd_grid = env_int("ITS_SPMV_VD_GRID", 768);   // its grid (3 w
 static int g_spmv_irr = env_int("ITS_SPMV_IRR", 1);             // 0 = never use the irregular-row kernel
 static int g_spmv_irr_grid = env_int("ITS_SPMV_IRR_GRID", 1280);
 static int g_spmv_irr_len = env_int("ITS_SPMV_IRR_LEN", IRR_ROW_LEN);   // longest row above which it is used
-static int g_spmv_nt = env_int("ITS_SPMV_NT", 0);
 static int g_spmv_bigplan = env_int("ITS_SPMV_BIGPLAN", 1);     // 0 = spmv_stream4_kernel on the ordinary plan too
 int spmv_tune(const char *name, int value)
 {
@@ -866,7 +865,6 @@ int spmv_tune(const char *name, int value)
     if (!strcmp(name, "spmv_irr_len")) { if (value < 1) return -1; g_spmv_irr_len = value; return 0; }
     if (!strcmp(name, "spmv_irr_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_irr_grid = value; return 0; }
     if (!strcmp(name, "spmv_bigplan")) { if (value < 0 || value > 1) return -1; g_spmv_bigplan = value; return 0; }
-    if (!strcmp(name, "spmv_nt")) { if (value < 0 || value > 3) return -1; g_spmv_nt = value; return 0; }
     return -2;
 }
 
