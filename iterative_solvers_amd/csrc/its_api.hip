@@ -749,7 +749,8 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     if (rc) return rc;
     if (h->precond == ITS_PRECOND_GS) { if ((rc = sweep(h, w, w))) return rc; }   // gmres.hpp:251
     // the Hessenberg column is written into pinned host memory when it fits there (slots 2048..), else copied
-    const bool hcol_pinned = k + 2 <= 2000 && getenv("ITS_READBACK_COPY") == nullptr;
+    static const bool use_copy = getenv("ITS_READBACK_COPY") != nullptr;
+    const bool hcol_pinned = k + 2 <= 2000 && !use_copy;
     double *hcol_out = hcol_pinned ? h->pinned + 2048 : h->hcol_dev;
     if (hcol_pinned) arm_pinned_word(hcol_out + (k + 1));
     // MGS (gmres.hpp:269-329): step j finishes w -= h_{j-1} v_{j-1} and starts h_j = w . v_j
