@@ -32,6 +32,9 @@ namespace its {
 // Row blocks are described by blk_desc[rb] = {first row, rows, first nnz, end nnz}.
 // --------------------------------------------------------------------------------------
 constexpr int S2_CAP = SPMV_NNZ_MAX + 8;
+// non-temporal hint on the col/val/row_ptr stream of spmv_stream4_kernel: measured a LOSS inside the CG loop
+// (2104 vs 2123 it/s), although those bytes are read once — kept as a switch for re-measurement
+constexpr int SPMV4_NT = 0;
 static_assert(SPMV_NNZ_MAX + 3 <= 2 * 4 * ITS_BLOCK, "staging is written for two slices of 4 entries per lane");
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -94,7 +97,8 @@ template <int EPI, bool DOT>
 __device__ __forceinline__ void epi_operands(const SpmvArgs &a, int row, double &e0, double &e1, double &e2)
 {
     if (EPI == EPI_STORE && DOT) e0 = a.dotv[row];
-    if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) e0 = a.b[row];
+    if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused)
+        e0 = a.b[row];
     if (EPI == EPI_JACOBI_SHIPPED) { e0 = a.D[row]; e1 = a.x[row]; e2 = a.b[row]; }
     if (EPI == EPI_SWEEP) { e0 = a.b[row]; e1 = a.D[row]; }
 }
@@ -388,15 +392,15 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream4_kernel(
         const int iA_ = base_ + 4 * t, iB_ = iA_ + 4 * ITS_BLOCK;                         \
         const int jA_ = iA_ < (d).w ? iA_ : 0, jB_ = iB_ < (d).w ? iB_ : 0;               \
         const int jr_ = t < ((d).y & 0xffff) ? (d).x + t : 0;                             \
-        if (IDX) R.cA.x = *reinterpret_cast<const int *>(cidx + jA_);                     \
-        else R.cA = ld_i4<0>(col + jA_);                                                  \
+        if (IDX) R.cA.x = ld_i1<SPMV4_NT>(reinterpret_cast<const int *>(cidx + jA_));     \
+        else R.cA = ld_i4<SPMV4_NT>(col + jA_);                                           \
         if (VD) R.cA.y = *reinterpret_cast<const int *>(vidx + jA_);                      \
-        else { R.vA0 = ld_d2<0>(val + jA_); R.vA1 = ld_d2<0>(val + jA_ + 2); }            \
-        if (IDX) R.cB.x = *reinterpret_cast<const int *>(cidx + jB_);                     \
-        else R.cB = ld_i4<0>(col + jB_);                                                  \
+        else { R.vA0 = ld_d2<SPMV4_NT>(val + jA_); R.vA1 = ld_d2<SPMV4_NT>(val + jA_ + 2); } \
+        if (IDX) R.cB.x = ld_i1<SPMV4_NT>(reinterpret_cast<const int *>(cidx + jB_));     \
+        else R.cB = ld_i4<SPMV4_NT>(col + jB_);                                           \
         if (VD) R.cB.y = *reinterpret_cast<const int *>(vidx + jB_);                      \
-        else { R.vB0 = ld_d2<0>(val + jB_); R.vB1 = ld_d2<0>(val + jB_ + 2); }            \
-        R.rp = rp[jr_];                                                                   \
+        else { R.vB0 = ld_d2<SPMV4_NT>(val + jB_); R.vB1 = ld_d2<SPMV4_NT>(val + jB_ + 2); } \
+        R.rp = ld_i1<SPMV4_NT>(rp + jr_);                                                 \
     } while (0)
     // four packed dictionary indices -> four (col - row) offsets
 #define S4_DECODE(w)                                                                      \
@@ -1271,6 +1275,17 @@ void launch_fill(double *out, double v, int64_t n, hipStream_t s)
 // ======================================================================================
 // CG vector updates (methods/cg.hpp:204-230) with the reductions fused in.
 // ======================================================================================
+// Cache policy of the vector passes.  A CG trip moves 2.5 GB through a 256 MB Infinity Cache and 32 MB of L2, so
+// what a pass leaves behind decides what the next pass finds.  A vector's LAST read of a trip, and every access to
+// x (touched once per trip, by the x/p pass only), carry the non-temporal hint, so they do not push out p (read by
+// the next SpMV), q and r (read by the next pass).  Measured on the 256^3 CG loop, cumulative: x loads + stores
+// 2041 -> 2115 it/s (x/p pass 108.6 -> 99.3 us, SpMV 318 -> 309 us), q and r loads of the r pass -> 2128, r load
+// of the x/p pass -> 2174.  NOT helped: the hint on the old-p load of the x/p pass (2154) and on the matrix
+// stream of the SpMV (2104).
+constexpr bool CG_NT_R = true;      // r pass: r read (last read of the old r)
+constexpr bool CG_NT_Q = true;      // r pass: q read (q is dead afterwards)
+constexpr bool CG_NT_XR = true;     // x/p pass: r read (last read of the trip)
+constexpr bool CG_NT_XP = false;    // x/p pass: old p read
 // Pass 1 of a CG trip: alpha = rr / (p.q); r -= alpha q; partial sums of r.r.  (x += alpha p needs p
 // once more and moves into pass 2, which reads p anyway: 64n bytes per trip instead of 72n; the
 // per-element operations and their order are those of cg.hpp:181-202, so the bits are unchanged.)
@@ -1288,8 +1303,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void cg_update_r_kernel(
     double2 *r2 = reinterpret_cast<double2 *>(r);
     const double2 *q2 = reinterpret_cast<const double2 *>(q);
     for (int64_t i = tid; i < n2; i += nth) {
-        double2 rv = r2[i];
-        const double2 qv = q2[i];
+        double2 rv = CG_NT_R ? ld_d2<1>(r + 2 * i) : r2[i];
+        const double2 qv = CG_NT_Q ? ld_d2<1>(q + 2 * i) : q2[i];
         rv.x = fma(-alpha, qv.x, rv.x); rv.y = fma(-alpha, qv.y, rv.y);    // cg.hpp:182
         r2[i] = rv;
         s0 = fma(rv.x, rv.x, s0); s1 = fma(rv.y, rv.y, s1);                // cg.hpp:186
@@ -1321,11 +1336,15 @@ __global__ __launch_bounds__(ITS_BLOCK) void cg_update_xp_kernel(
     double2 *p2 = reinterpret_cast<double2 *>(p), *x2 = reinterpret_cast<double2 *>(x);
     const double2 *r2 = reinterpret_cast<const double2 *>(r);
     for (int64_t i = tid; i < n2; i += nth) {
-        double2 pv = p2[i], xv = x2[i];
-        const double2 rv = r2[i];
+        double2 pv = CG_NT_XP ? ld_d2<1>(p + 2 * i) : p2[i];
+        const v2d_t xl = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(x2 + i));
+        double2 xv = make_double2(xl.x, xl.y);
+        const double2 rv = CG_NT_XR ? ld_d2<1>(r + 2 * i) : r2[i];
         xv.x = fma(alpha, pv.x, xv.x); xv.y = fma(alpha, pv.y, xv.y);      // cg.hpp:181
         pv.x = fma(beta, pv.x, rv.x); pv.y = fma(beta, pv.y, rv.y);        // cg.hpp:202
-        x2[i] = xv; p2[i] = pv;
+        v2d_t xs; xs.x = xv.x; xs.y = xv.y;
+        __builtin_nontemporal_store(xs, reinterpret_cast<v2d_t *>(x2 + i));
+        p2[i] = pv;
     }
     for (int64_t i = 2 * n2 + tid; i < n; i += nth) {
         const double pv = p[i];
@@ -1351,6 +1370,9 @@ void launch_cg_update_xp(double *x, double *p, const double *r, int64_t n, const
 // ======================================================================================
 // GMRES: modified Gram-Schmidt as fused "finish previous axpy + start next dot" steps.
 // ======================================================================================
+// v_prev is read for the last time in this trip: the non-temporal hint keeps it from pushing w and v_next out
+// of the caches (27-pt 128^3 GMRES(50): 0.503 -> 0.451 ms per trip; two elements per lane before that: 0.540 -> 0.503)
+constexpr bool MGS_NT_PREV = true;
 __global__ __launch_bounds__(ITS_BLOCK) void mgs_step_kernel(
     double *__restrict__ w, const double *__restrict__ v_prev, const double *__restrict__ part_prev,
     int prev_is_scalar, const double *__restrict__ v_next, double *__restrict__ part_next,
@@ -1362,12 +1384,28 @@ __global__ __launch_bounds__(ITS_BLOCK) void mgs_step_kernel(
     const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
     double s0 = 0.0;
-    for (int64_t i = tid; i < n; i += nth) {
-        double wi = w[i];
-        if (v_prev) { wi = fma(-h, v_prev[i], wi); w[i] = wi; }            // gmres.hpp:314
-        s0 = fma(wi, v_next ? v_next[i] : wi, s0);                         // gmres.hpp:286 / :359
+    // two elements per lane (solver vectors are 256-byte aligned, ldv even); v_prev is read for the last time
+    // this trip: non-temporal (MGS_NT_PREV)
+    const int64_t n2 = (al16(w) && (!v_prev || al16(v_prev)) && (!v_next || al16(v_next))) ? n / 2 : 0;
+    double2 *w2 = reinterpret_cast<double2 *>(w);
+    const double2 *vn2 = reinterpret_cast<const double2 *>(v_next);
+    double s1 = 0.0;
+    for (int64_t i = tid; i < n2; i += nth) {
+        double2 wi = w2[i];
+        if (v_prev) {
+            const double2 vp = MGS_NT_PREV ? ld_d2<1>(v_prev + 2 * i) : *reinterpret_cast<const double2 *>(v_prev + 2 * i);
+            wi.x = fma(-h, vp.x, wi.x); wi.y = fma(-h, vp.y, wi.y);        // gmres.hpp:314
+            w2[i] = wi;
+        }
+        const double2 vn = v_next ? vn2[i] : wi;
+        s0 = fma(wi.x, vn.x, s0); s1 = fma(wi.y, vn.y, s1);                // gmres.hpp:286 / :359
     }
-    const double bs = block_sum(s0, s_red);
+    for (int64_t i = 2 * n2 + tid; i < n; i += nth) {
+        double wi = w[i];
+        if (v_prev) { wi = fma(-h, v_prev[i], wi); w[i] = wi; }
+        s0 = fma(wi, v_next ? v_next[i] : wi, s0);
+    }
+    const double bs = block_sum(s0 + s1, s_red);
     store_partial(part_next, bs);
     if (threadIdx.x == 0 && blockIdx.x == 0 && h_out && v_prev) h_out[0] = h;
 }
@@ -1381,7 +1419,13 @@ __global__ __launch_bounds__(ITS_BLOCK) void mgs_normalize_kernel(
     const double inv = 1.0 / nrm;                                          // gmres.hpp:389
     const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
-    for (int64_t i = tid; i < n; i += nth) v_out[i] = w[i] * inv;
+    const int64_t n2 = (al16(w) && al16(v_out)) ? n / 2 : 0;
+    double2 *o2 = reinterpret_cast<double2 *>(v_out);
+    for (int64_t i = tid; i < n2; i += nth) {
+        const double2 wv = ld_d2<1>(w + 2 * i);                             // last read of w
+        o2[i] = make_double2(wv.x * inv, wv.y * inv);
+    }
+    for (int64_t i = 2 * n2 + tid; i < n; i += nth) v_out[i] = w[i] * inv;
     if (blockIdx.x == 0 && threadIdx.x == 0 && h_out) h_out[0] = nrm;
 }
 
