@@ -144,7 +144,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
     const int *__restrict__ col, const double *__restrict__ val, int n_rows,
     const unsigned char *__restrict__ cidx, const int *__restrict__ off_dict, SpmvArgs a)
 {
-    constexpr int NT = 0;
+    // bit 0: non-temporal col/val/row_ptr loads (a loss: plain SpMV 0.291 -> 0.324 ms); bit 1: non-temporal store of
+    // the result (plain 0.291 -> 0.285 ms, Jacobi trip 0.341 -> 0.337 ms) — not for the sweep, whose result the
+    // next level gathers right away
+    constexpr int NT = EPI == EPI_SWEEP ? 0 : 2;
     // IDX == 2: 9 instead of 12 bytes of LDS per entry, so four workgroups per CU still fit with blocks of up to
     // SPMV_NNZ_BIG entries (full 256-row blocks for 7-pt)
     constexpr int CAP = IDX == 2 ? SPMV_NNZ_BIG + 8 : S2_CAP;
