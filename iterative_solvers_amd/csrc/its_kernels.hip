@@ -1283,8 +1283,8 @@ void launch_fill(double *out, double v, int64_t n, hipStream_t s)
 // x (touched once per trip, by the x/p pass only), carry the non-temporal hint, so they do not push out p (read by
 // the next SpMV), q and r (read by the next pass).  Measured on the 256^3 CG loop, cumulative: x loads + stores
 // 2041 -> 2115 it/s (x/p pass 108.6 -> 99.3 us, SpMV 318 -> 309 us), q and r loads of the r pass -> 2128, r load
-// of the x/p pass -> 2174.  NOT helped: the hint on the old-p load of the x/p pass (2154) and on the matrix
-// stream of the SpMV (2104).
+// of the x/p pass -> 2174.  NOT helped: the hint on the old-p load of the x/p pass (2154), on the matrix stream
+// of the SpMV (2104), on the stores of q (2174), r (2159) and p (2173).
 constexpr bool CG_NT_R = true;      // r pass: r read (last read of the old r)
 constexpr bool CG_NT_Q = true;      // r pass: q read (q is dead afterwards)
 constexpr bool CG_NT_XR = true;     // x/p pass: r read (last read of the trip)
