@@ -4,7 +4,8 @@
 #   HBM traffic counters (separate --pmc passes, FETCH_SIZE and WRITE_SIZE cannot share one).
 R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/$R      # gpurun merges into what is already there: stale traces would be picked up
+rm -rf gpurun_out/$R      # (on the GPU box; gpurun MERGES results into the local gpurun_out/: remove the local
+                          # gpurun_out/$R before the call as well, or stale traces sit beside the new ones)
 mkdir -p gpurun_out/$R
 timeout -k 10 400 python3 bench.py > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -- python3 bench.py --no-cpu > gpurun_out/$R/trace.log 2>&1 || exit 1
