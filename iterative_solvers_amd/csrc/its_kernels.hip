@@ -35,6 +35,9 @@ constexpr int S2_CAP = SPMV_NNZ_MAX + 8;
 // non-temporal hint on the col/val/row_ptr stream of spmv_stream4_kernel: measured a LOSS inside the CG loop
 // (2104 vs 2123 it/s), although those bytes are read once — kept as a switch for re-measurement
 constexpr int SPMV4_NT = 0;
+// the sweep reads its right-hand side and the diagonal once per trip, for the last time: non-temporal (multicolour GS
+// trip at 256^3 0.551 -> 0.546 ms)
+constexpr bool SWEEP_NT = true;
 static_assert(SPMV_NNZ_MAX + 3 <= 2 * 4 * ITS_BLOCK, "staging is written for two slices of 4 entries per lane");
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -100,7 +103,7 @@ __device__ __forceinline__ void epi_operands(const SpmvArgs &a, int row, double 
     if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused)
         e0 = a.b[row];
     if (EPI == EPI_JACOBI_SHIPPED) { e0 = a.D[row]; e1 = a.x[row]; e2 = a.b[row]; }
-    if (EPI == EPI_SWEEP) { e0 = a.b[row]; e1 = a.D[row]; }
+    if (EPI == EPI_SWEEP) { e0 = SWEEP_NT ? __builtin_nontemporal_load(a.b + row) : a.b[row]; e1 = SWEEP_NT ? __builtin_nontemporal_load(a.D + row) : a.D[row]; }
 }
 
 template <int EPI, bool DOT>
