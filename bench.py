@@ -148,8 +148,8 @@ def main():
                                      colg - n)).astype(np.int32)
             h.upload_crs(rp, coll, val, capi.MAT_A, fmt, n_cols=n + 2 * P)
             send_idx = np.concatenate([np.arange(n - P, n), np.arange(0, P)]).astype(np.int32)   # own top, own bottom
-            nbr = np.zeros(1, np.int32); off = np.array([0, 2 * P], np.int32)
-            h.check(h.L.its_dist_setup(h.h, 1, nbr.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+            nbr = np.zeros(2, np.int32); off = np.array([0, P, 2 * P], np.int32)   # two "neighbours", one plane each, as at N > 1
+            h.check(h.L.its_dist_setup(h.h, 2, nbr.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
                                        send_idx.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p)), "its_dist_setup")
         else:
             D.upload_slab(h, rdzv, world * n, rank * n, rp, colg, val, fmt)

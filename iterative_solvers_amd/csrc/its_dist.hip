@@ -31,6 +31,9 @@ struct DistPlan {
     bool plan_ready = false;
     int n_nbr = 0, n_send = 0, n_halo = 0;
     std::vector<int> nbr, send_off, recv_off;
+    // when every neighbour's send list is one ascending run of local rows (the planes of a slab), entries are sent
+    // straight out of the vector: send_first[k] = first row of the run; empty = pack through send_buf
+    std::vector<int> send_first;
     int *send_idx = nullptr;                 // device
     double *send_buf = nullptr;              // device
     double *host_send = nullptr, *host_recv = nullptr, *host_sc = nullptr;   // pinned (HOST transport)
@@ -163,6 +166,14 @@ extern "C" int its_dist_setup(its_handle *h, int n_nbr, const int *nbr, const in
     }
     for (int i = 0; i < d->n_send; ++i)
         if (send_idx[i] < 0 || send_idx[i] >= n_loc) FAIL(h, ITS_EINVAL, "send index outside the owned rows");
+    d->send_first.clear();
+    {
+        bool runs = n_nbr > 0;
+        for (int k = 0; k < n_nbr && runs; ++k)
+            for (int i = d->send_off[k] + 1; i < d->send_off[k + 1] && runs; ++i) runs = send_idx[i] == send_idx[i - 1] + 1;
+        if (runs)
+            for (int k = 0; k < n_nbr; ++k) d->send_first.push_back(d->send_off[k + 1] > d->send_off[k] ? send_idx[d->send_off[k]] : 0);
+    }
     dfree(d->send_idx); dfree(d->send_buf);
     if (dalloc(h, &d->send_idx, d->n_send) || dalloc(h, &d->send_buf, d->n_send)) return ITS_EHIP;
     if (d->n_send) HIPCHK(h, hipMemcpy(d->send_idx, send_idx, (size_t)d->n_send * sizeof(int), hipMemcpyHostToDevice));
@@ -209,7 +220,8 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
     const CsrDev &A = h->mat[ITS_MAT_A];
     double *x = const_cast<double *>(a.x);          // solver vectors are ours; the halo tail is scratch
     const int n_loc = A.n_rows;
-    if (d->n_send) {
+    const bool direct_send = d->transport == 1 && !d->send_first.empty();
+    if (d->n_send && !direct_send) {
         hipLaunchKernelGGL(pack_kernel, dim3((d->n_send + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, h->stream,
                            a.x, d->send_idx, d->send_buf, d->n_send);
         HIPCHK(h, hipGetLastError());
@@ -228,7 +240,7 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
             NCCLCHK(h, ncclGroupStart());
             for (int k = 0; k < d->n_nbr; ++k) {
                 const int ns = d->send_off[k + 1] - d->send_off[k], nr = d->recv_off[k + 1] - d->recv_off[k];
-                if (ns) NCCLCHK(h, ncclSend(d->send_buf + d->send_off[k], ns, ncclDouble, d->nbr[k], d->comm_halo, h->stream));
+                if (ns) NCCLCHK(h, ncclSend(direct_send ? a.x + d->send_first[k] : d->send_buf + d->send_off[k], ns, ncclDouble, d->nbr[k], d->comm_halo, h->stream));
                 if (nr) NCCLCHK(h, ncclRecv(x + n_loc + d->recv_off[k], nr, ncclDouble, d->nbr[k], d->comm_halo, h->stream));
             }
             NCCLCHK(h, ncclGroupEnd());
@@ -243,7 +255,7 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
             NCCLCHK(h, ncclGroupStart());
             for (int k = 0; k < d->n_nbr; ++k) {
                 const int ns = d->send_off[k + 1] - d->send_off[k], nr = d->recv_off[k + 1] - d->recv_off[k];
-                if (ns) NCCLCHK(h, ncclSend(d->send_buf + d->send_off[k], ns, ncclDouble, d->nbr[k], d->comm_halo, d->cstream));
+                if (ns) NCCLCHK(h, ncclSend(direct_send ? a.x + d->send_first[k] : d->send_buf + d->send_off[k], ns, ncclDouble, d->nbr[k], d->comm_halo, d->cstream));
                 if (nr) NCCLCHK(h, ncclRecv(x + n_loc + d->recv_off[k], nr, ncclDouble, d->nbr[k], d->comm_halo, d->cstream));
             }
             NCCLCHK(h, ncclGroupEnd());

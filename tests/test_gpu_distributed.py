@@ -115,8 +115,9 @@ def _periodic_z_laplacian(N, diag=7.0):
     return n, to_crs(cg_), to_crs(cl_), send_idx
 
 
+@pytest.mark.parametrize("two_entries", [False, True])
 @pytest.mark.parametrize("overlap", [0, 1])
-def test_rccl_send_recv_loopback_on_one_gpu(overlap):
+def test_rccl_send_recv_loopback_on_one_gpu(overlap, two_entries):
     """The RCCL halo exchange (pack kernel -> grouped ncclSend/ncclRecv on the side stream -> boundary SpMV after
     the halo event) run for real on ONE GPU: a one-rank world whose only neighbour is itself, carrying the
     wrap-around planes of a z-periodic Laplacian.  Checked against the same system as one global matrix."""
@@ -135,8 +136,11 @@ def test_rccl_send_recv_loopback_on_one_gpu(overlap):
                 h.check(h.L.its_comm_unique_id(C.byref(ids, 128)), "its_comm_unique_id")
                 h.check(h.L.its_comm_init(h.h, 0, 1, ids), "its_comm_init")
                 h.upload_crs(rpl, coll, vall, n_cols=n + 2 * P)
-                nbr = np.zeros(1, np.int32); off = np.array([0, 2 * P], np.int32)
-                h.check(h.L.its_dist_setup(h.h, 1, nbr.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                # one neighbour entry carrying both planes (two runs of rows: packed through the send buffer), or two
+                # entries of one plane each (an ascending run each: sent straight out of the vector)
+                nbr = np.zeros(2 if two_entries else 1, np.int32)
+                off = np.array([0, P, 2 * P] if two_entries else [0, 2 * P], np.int32)
+                h.check(h.L.its_dist_setup(h.h, len(nbr), nbr.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
                                            send_idx.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p)), "its_dist_setup")
             else:
                 h.upload_crs(rpg, colg, valg)
