@@ -599,7 +599,7 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         if (restart_len < 1) FAIL(h, ITS_EINVAL, "restart_len < 1");
         const int m = h->m = restart_len;
         dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
-        if (dalloc(h, &h->V, ne * (size_t)(m + 1)) || dalloc(h, &h->hcol_dev, m + 2) || dalloc(h, &h->y_dev, m + 1)) return ITS_EHIP;
+        if (dalloc(h, &h->V, (((size_t)ne + 31) & ~(size_t)31) * (size_t)(m + 1)) || dalloc(h, &h->hcol_dev, m + 2) || dalloc(h, &h->y_dev, m + 1)) return ITS_EHIP;
         h->Rm.assign((size_t)(m + 1) * m, 0.0); h->g.assign(m + 1, 0.0);
         h->cs.assign(m, 0.0); h->sn.assign(m, 0.0); h->hcol.assign(m + 2, 0.0);
         if (const char *e = getenv("ITS_GMRES_GIVENS")) h->gmres_givens = !strcmp(e, "dense") || !strcmp(e, "1");
@@ -651,6 +651,10 @@ static int wait_pinned_word(its_handle *h, const double *slot_d)
     if (!arrived) HIPCHK(h, hipStreamSynchronize(h->stream));
     return ITS_OK;
 }
+
+// leading dimension of the Krylov basis V: the vector length (owned + halo entries) rounded up to 32 doubles, so
+// that every basis vector starts 256-byte aligned and the vector kernels keep their two-elements-per-lane path
+static inline size_t krylov_ld(const its_handle *h) { return ((size_t)std::max(h->n_ext, h->n) + 31) & ~(size_t)31; }
 
 // ---------------------------------------------------------------------------------------
 // one trip of each method, enqueued on h->stream; the residual scalar lands in res_out (device)
@@ -748,7 +752,7 @@ static int trip_gs(its_handle *h, double *res_out)
 static int trip_gmres(its_handle *h, int iter_count, double *res_host)
 {
     const int n = h->n, m = h->m;
-    const size_t ld = (size_t)std::max(h->n_ext, n);
+    const size_t ld = krylov_ld(h);
     const int k = iter_count - h->restart_count * m;                  // gmres.hpp:113
     if (k < 0 || k >= m) FAIL(h, ITS_ESTATE, "GMRES inner index out of range: restart missing?");
     double *w = h->tmp;
@@ -841,7 +845,7 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
 static int gmres_get_x(its_handle *h, double *x_out, const double *x0, int iter_count)
 {
     const int n = h->n, m = h->m;
-    const size_t ld = (size_t)std::max(h->n_ext, n);
+    const size_t ld = krylov_ld(h);
     const int k = iter_count - h->restart_count * m;                  // :880
     std::vector<double> y(m + 1, 0.0);
     for (int row = k; row >= 0; --row) {                              // :901-916
