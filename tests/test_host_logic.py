@@ -183,3 +183,17 @@ def test_library_refuses_to_run_without_a_gpu():
         assert rc != 0 and not h.value
     elif rc == 0:
         L.its_destroy(h)
+
+
+def test_makefile_objects_depend_on_every_header():
+    """A header missing from the object rule leaves stale objects behind a layout change (its_dist.o once kept the
+    old its_handle layout and read the communicator pointer from the wrong offset: a GPU memory fault)."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "iterative_solvers_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    rule = re.search(r"^%\.o: %\.hip (.*)$", mk, re.M).group(1).split()
+    for hdr in glob.glob(os.path.join(csrc, "*.h")):
+        assert os.path.basename(hdr) in rule, f"{os.path.basename(hdr)} is not a prerequisite of %.o"
