@@ -63,6 +63,7 @@ struct its_handle {
     bool ahead = false;
     bool setup_done = false, residual_done = false;
     double last_residual = 0.0;
+    int watch_misses = 0;                        // wait_pinned_word: times the watched word did not arrive within its window
     // triangular sweep schedule (levels of L; colours when the matrix was colour-permuted)
     std::vector<int> level_ptr;           // host offsets into level_rows
     std::vector<int> level_nshort;            // rows of each level with <= SWEEP_SHORT entries in L (listed first)
