@@ -80,6 +80,54 @@ def cpu_baseline(rp, col, val, n, budget_s=15.0):
                       f"on the same {n}-row system, oracle/libits_oracle.so with {threads} OpenMP threads"}
 
 
+def spawn_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (rank r -> GPU r), each with
+    the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* variables torch.distributed.run would set, relay rank 0's one
+    JSON line, and fail if any rank fails.  This parent never touches the GPU (no HIP call, no library load), so
+    no process that has initialised a device is ever replaced or forked."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    timeout = float(os.environ.get("ITS_BENCH_SPAWN_TIMEOUT", "1500"))
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   ITS_BENCH_CHILD="1")
+        env.pop("NCCL_DEBUG", None)                     # stdout carries exactly one line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    deadline = time.time() + timeout
+    rc = 0
+    out0 = b""
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        sys.stderr.write(f"bench.py: ranks did not finish within {timeout:.0f} s "
+                         "(stuck in communicator set-up? every rank needs a GPU of its own unless ITS_BENCH_TRANSPORT=host)\n")
+        rc = 124
+    for r, p in enumerate(procs):
+        if p.poll() is None:
+            p.send_signal(signal.SIGKILL)               # exactly the processes started above
+            p.wait()
+        if p.returncode != 0 and rc == 0:
+            sys.stderr.write(f"bench.py: rank {r} exited with status {p.returncode}\n")
+            rc = p.returncode if p.returncode > 0 else 1
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, got {len(lines)}\n")
+        rc = 1
+    if rc == 0:
+        print(lines[0], flush=True)
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +139,9 @@ def main():
     ap.add_argument("--spmv-reps", type=int, default=50)
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a.gpus, sys.argv[1:])               # never returns
+
     # NOTE: this process never imports torch — PyTorch's wheel bundles a second ROCm runtime
     # (7.0) that must not share an address space with the /opt/rocm runtime libits_hip.so uses
     # (iterative_solvers_amd/rendezvous.py explains).  The launcher may still be
@@ -101,8 +152,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and a.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != a.gpus and not (world == 1 and a.gpus <= 1):
+        raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE={world}")
     rdzv = Rendezvous(rank, world)
     dist = rdzv if world > 1 else None
     fmt = {"exact": capi.FMT_CSR_EXACT, "vector": capi.FMT_CSR_VECTOR, "sell": capi.FMT_SELL}[a.format]

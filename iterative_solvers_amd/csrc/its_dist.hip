@@ -1,8 +1,12 @@
 // its_dist.hip — multi-GPU layer of libits_hip.so: one process per GPU, matrix row-block
-// partitioned.  Per SpMV: pack the x entries the neighbours need, exchange them
-// (RCCL send/recv over xGMI on a side stream) WHILE the interior row blocks are multiplied, then
-// multiply the boundary row blocks.  Per dot/norm: one RCCL all-reduce of a device scalar on the
-// compute stream — no host synchronisation anywhere in a trip.
+// partitioned.  Per SpMV (default, "dist_overlap" 0): pack the x entries the neighbours need
+// (skipped when every send list is one ascending run of rows: sent straight out of the vector), exchange them with
+// grouped RCCL send/recv over xGMI ON THE COMPUTE STREAM, then ONE product over the ordinary row-block plan.
+// Exchange-first is the default because it measured faster than hiding the exchange: beside a persistent SpMV
+// grid the RCCL kernel's workgroups wait 100-330 us for CUs.  The overlapped form (exchange on a
+// high-priority side stream beside the interior row blocks, boundary blocks after the halo event) is kept behind
+// option "dist_overlap" 1.  Per dot/norm: one RCCL all-reduce of the ITS_NPART partials on the compute stream —
+// no host synchronisation anywhere in a trip.
 //
 // The reference has no counterpart (single process; "TODO: MPI", main.cpp:94).  The partition is
 // planned on the host (iterative_solvers_amd/distributed.py) and arrives through its_dist_setup.
@@ -16,7 +20,20 @@
 #include "its_handle.h"
 
 #include <rccl/rccl.h>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+static int env_seconds(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && atoi(e) > 0 ? atoi(e) : dflt;
+}
 
 struct DistPlan {
     int rank = 0, world = 1;
@@ -121,8 +138,40 @@ extern "C" int its_comm_init(its_handle *h, int rank, int world, const void *ids
     memcpy(&id1, (const char *)ids256 + 128, 128);
     // two communicators: halo send/recv run on the side stream, all-reduces on the compute stream;
     // operations of ONE communicator must not be in flight on two streams at once
-    NCCLCHK(h, ncclCommInitRank(&d->comm_halo, world, id0, rank));
-    NCCLCHK(h, ncclCommInitRank(&d->comm_red, world, id1, rank));
+    // ncclCommInitRank blocks until every rank has joined; a rank that never arrives (crashed, wrong WORLD_SIZE,
+    // two ranks on one device) would hang the others for good.  The blocking calls therefore run on a helper
+    // thread (bound to this handle's device) that the caller waits on for ITS_COMM_TIMEOUT_S (default 180 s).
+    HIPCHK(h, hipSetDevice(h->device));
+    int dev_count = 0;
+    HIPCHK(h, hipGetDeviceCount(&dev_count));
+    const int timeout_s = std::max(1, env_seconds("ITS_COMM_TIMEOUT_S", 180));
+    struct InitState { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r0 = ncclSuccess, r1 = ncclSuccess;
+                       ncclComm_t c0 = nullptr, c1 = nullptr; };
+    auto st = std::make_shared<InitState>();
+    const int device = h->device;
+    std::thread([st, id0, id1, world, rank, device]() {
+        ncclResult_t r0 = ncclSystemError, r1 = ncclSystemError;
+        ncclComm_t c0 = nullptr, c1 = nullptr;
+        if (hipSetDevice(device) == hipSuccess) {
+            r0 = ncclCommInitRank(&c0, world, id0, rank);
+            r1 = r0 == ncclSuccess ? ncclCommInitRank(&c1, world, id1, rank) : r0;
+        }
+        std::lock_guard<std::mutex> lk(st->mu);
+        st->r0 = r0; st->r1 = r1; st->c0 = c0; st->c1 = c1; st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lk(st->mu);
+        if (!st->cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return st->done; })) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "ncclCommInitRank: rank %d of %d on device %d (of %d visible) did not complete within %d s "
+                     "(a peer rank missing, or two ranks on one GPU?)", rank, world, device, dev_count, timeout_s);
+            FAIL(h, ITS_ECOMM, msg);
+        }
+        if (st->r0 != ncclSuccess) FAIL(h, ITS_ECOMM, std::string("ncclCommInitRank (halo): ") + ncclGetErrorString(st->r0));
+        if (st->r1 != ncclSuccess) FAIL(h, ITS_ECOMM, std::string("ncclCommInitRank (reductions): ") + ncclGetErrorString(st->r1));
+        d->comm_halo = st->c0; d->comm_red = st->c1;
+    }
     d->rank = rank; d->world = world; d->transport = 1;
     return ITS_OK;
 }
@@ -144,6 +193,7 @@ extern "C" int its_dist_setup(its_handle *h, int n_nbr, const int *nbr, const in
                               const int *send_idx, const int *recv_off)
 {
     if (!h || n_nbr < 0 || (n_nbr > 0 && (!nbr || !send_off || !recv_off))) return ITS_EINVAL;
+    if (n_nbr > 0 && send_off[n_nbr] > 0 && !send_idx) FAIL(h, ITS_EINVAL, "send_idx is null but send_off lists entries to send");
     if (!h->dist || h->dist->transport == 0) FAIL(h, ITS_ESTATE, "its_comm_init first");
     if (!h->have[ITS_MAT_A]) FAIL(h, ITS_ESTATE, "upload the local matrix first");
     HIPCHK(h, hipSetDevice(h->device));

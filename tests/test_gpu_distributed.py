@@ -155,3 +155,21 @@ def test_rccl_send_recv_loopback_on_one_gpu(overlap, two_entries):
     a, b = np.array(hists[0][1]), np.array(hists[1][1])
     assert np.all(np.abs(a - b) <= 1e-11 * np.maximum(a, 1e-3 * a[0]))
     assert np.max(np.abs(hists[0][2] - hists[1][2])) <= 1e-11 * np.max(np.abs(hists[0][2]))
+
+
+def test_bench_spawns_its_own_ranks_host_transport():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two fresh rank processes itself (it never
+    touches the GPU) and relays rank 0's single JSON line.  HOST transport puts both ranks on GPU 0, so the whole
+    N > 1 flow — rendezvous, partition plan, halo exchange, all-reduced partials, max-over-ranks timing — runs on
+    the one-GPU box; without ITS_BENCH_TRANSPORT the same command is the RCCL path of the scaling bench."""
+    env = dict(os.environ, ITS_BENCH_TRANSPORT="host", ITS_BENCH_SPAWN_TIMEOUT="100")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "4",
+                        "--warmup", "2", "--grid", "32", "--no-cpu"], env=env, capture_output=True, text=True, timeout=115)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert out["metric"] == "cg_iters_per_sec" and out["value"] > 0 and out["jacobi"]["value"] > 0

@@ -197,3 +197,21 @@ def test_makefile_objects_depend_on_every_header():
     rule = re.search(r"^%\.o: %\.hip (.*)$", mk, re.M).group(1).split()
     for hdr in glob.glob(os.path.join(csrc, "*.h")):
         assert os.path.basename(hdr) in rule, f"{os.path.basename(hdr)} is not a prerequisite of %.o"
+
+
+def test_bench_spawn_reports_a_failing_rank(tmp_path):
+    import sys
+    """bench.py --gpus N without a launcher spawns its own ranks; a rank that dies (here: no GPU in this
+    container, its_create fails) must make the parent exit non-zero without printing a JSON line."""
+    import subprocess
+    env = dict(os.environ, ITS_BENCH_SPAWN_TIMEOUT="60")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    import shutil
+    if shutil.which("rocminfo") and subprocess.run(["rocminfo"], capture_output=True).returncode == 0:
+        pytest.skip("a GPU is visible: the failure path is not reachable this way")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--grid", "8", "--no-cpu"], env=env, capture_output=True, text=True, timeout=100)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "rank" in p.stderr
