@@ -38,30 +38,50 @@ def spmv_bytes(n, nnz):
 
 
 def cg_iter_bytes(n, nnz):
-    """SpMV + 9 vector passes (x,p->x; r,Ap->r with fused dot; r,p->p) = SpMV + 72 n."""
+    """SURVEY.md §8d's accounting of one CG trip: SpMV + 9 vector passes (x,p->x; r,Ap->r with fused dot; r,p->p) =
+    SpMV + 72 n.  (The implementation moves 64 n: `cg_GBps_streamed` in the JSON line prices that.)"""
     return spmv_bytes(n, nnz) + 72 * n
 
 
+def kernel_sources_hash():
+    """sha256 over the HIP sources of the library: what a PMC summary must have been taken with to describe the
+    kernels this run launches (tests/profile_run.sh stamps it into the summary it writes)."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "iterative_solvers_amd", "csrc", "*.h*"))):
+        hsh.update(os.path.basename(f).encode()); hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the kernel from the newest committed PMC summary (profiles/*pmc_summary.txt,
+    """(bytes per launch, source note) of the kernel from the newest committed PMC summary (profiles/*pmc_summary.txt,
     produced by tests/profile_run.sh: separate FETCH_SIZE / WRITE_SIZE passes).  gfx950 correction from
-    MI355X_MICROARCH.md: FETCH_SIZE (KB) counts half the bytes of wide coalesced reads -> doubled;
-    WRITE_SIZE (KB) is exact.  None if no summary is present."""
+    MI355X_MICROARCH.md: FETCH_SIZE (KB) counts half the bytes of wide coalesced reads -> doubled; WRITE_SIZE (KB)
+    is exact.  The summary carries the hash of the kernel sources it was taken with: when the sources here differ
+    (or the summary has no stamp, or does not list the kernel) the traffic is None and the note says why — a
+    counter value from other code is never reported as this run's."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.txt")))
     if not files:
-        return None
+        return None, "no profiles/*pmc_summary.txt"
     fetch = write = None
+    stamp = None
     for line in open(files[-1]):
-        if kernel_substr in line:
+        if line.startswith("# kernel_sources_sha256="):
+            stamp = line.split("=", 1)[1].strip()
+        if kernel_substr in line and "avg=" in line:
             kb = float(line.split("avg=")[1].split("KB")[0])
             if line.startswith("FETCH_SIZE"):
                 fetch = kb
             elif line.startswith("WRITE_SIZE"):
                 write = kb
+    name = os.path.relpath(files[-1], ROOT)
+    if stamp != kernel_sources_hash():
+        return None, f"{name} was taken with other kernel sources ({stamp}); re-run tests/profile_run.sh"
     if fetch is None or write is None:
-        return None
-    return 2.0 * fetch * 1024 + write * 1024
+        return None, f"{name} does not list {kernel_substr}"
+    return 2.0 * fetch * 1024 + write * 1024, f"{name} (kernel sources {stamp}; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
 
 
 def cpu_baseline(rp, col, val, n, budget_s=15.0):
@@ -137,7 +157,11 @@ def main():
     ap.add_argument("--format", default="exact", choices=["exact", "vector", "sell"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--print-source-hash", action="store_true", help="print the kernel-source hash PMC summaries are stamped with")
     a = ap.parse_args()
+    if a.print_source_hash:
+        print(kernel_sources_hash())
+        return
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a.gpus, sys.argv[1:])               # never returns
@@ -248,13 +272,14 @@ def main():
             # launch duration is what rocprofv3 --stats reports for the same command
             k_ms = inloop_spmv_ms
             ach = spmv_bytes(n, nnz) / (k_ms * 1e-3) / 1e9
+            kname, streamed = h.spmv_kernel_info(capi.MAT_A, True) if fmt == capi.FMT_CSR_EXACT else (a.format, spmv_bytes(n, nnz))
+            traffic, tnote = pmc_traffic(kname + "<") if (fmt == capi.FMT_CSR_EXACT and world == 1 and N == 256) else (None, "not the C2 single-GPU exact run")
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic("spmv_stream4_kernel<0, true, 1>") if (fmt == capi.FMT_CSR_EXACT and world == 1 and N == 256) else None,
-                    "kernel": "its::spmv_stream4_kernel<0, true, 1> (CSR SpMV + fused p.Ap partials, 1-byte offset stream)" if fmt == capi.FMT_CSR_EXACT else a.format,
+                    "traffic": traffic, "traffic_source": tnote,
+                    "kernel": f"its::{kname} (CSR SpMV fused with the p.Ap partial sums)",
                     "kernel_ms": k_ms, "algorithmic_bytes": spmv_bytes(n, nnz),
-                    # what the kernel is asked to move: the 7-pt matrix has 7 distinct col-row offsets, so the
-                    # exact kernel streams a 1-byte offset index instead of the 4-byte column (lossless)
-                    "streamed_bytes": spmv_bytes(n, nnz) - (3 * nnz if (fmt == capi.FMT_CSR_EXACT and os.environ.get("ITS_SPMV_IDX", "1") != "0") else 0)}
+                    # what the kernel is asked to move in its own (lossless) storage form of the same matrix
+                    "streamed_bytes": streamed}
             for nm, f in ((("exact", capi.FMT_CSR_EXACT), ("vector", capi.FMT_CSR_VECTOR)) if (world == 1 and not force_dist) else ()):
                 h.spmv_timed(xd, yd, f, reps=3)
                 ms = h.spmv_timed(xd, yd, f, reps=a.spmv_reps)
@@ -283,6 +308,9 @@ def main():
                                       else ("single GPU, RCCL loopback rehearsal of the N > 1 path" if loopback else "single GPU")},
             "cg_GBps_algorithmic": cg_iter_bytes(n, nnz) * its_per_s / 1e9,
             "cg_frac_of_hbm_peak": cg_iter_bytes(n, nnz) * its_per_s / 1e9 / HBM_PEAK_GBS,
+            # bytes the trip actually asks for: the SpMV in its own storage form + 8 vector passes (x += alpha p runs
+            # inside the p pass, so a trip is 64 n, not the 72 n of SURVEY.md §8d's accounting above)
+            "cg_GBps_streamed": ((roof["streamed_bytes"] + 64 * n) * its_per_s / 1e9) if roof else None,
             "async_loop_ms_per_step": async_ms,
             "last_residual": float(res[-1]),
             "spmv": spmv_all, "setup_seconds": t_gen,

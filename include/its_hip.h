@@ -84,6 +84,11 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                  column when the matrix has <= 256 distinct col - row; 0 = always the plain col stream
  *   "spmv_valdict" 1 = also stream values as 1-byte dictionary indices (<= 256 distinct fp64 values);
  *                  default 0
+ *   "spmv_ell"     1 (default) = matrices with rows of <= 8 entries and <= 15 distinct col - row (5-/7-point
+ *                  stencils, also halo-renumbered) run on a sliced ELL image built at upload (its_ell.hip): 8 W + 4
+ *                  bytes per row instead of 9 nnz + 4, no LDS staging; 0 = the CRS stream kernels
+ *   "spmv_ell_grid" workgroups (default 512 = 2 per CU), "spmv_ell_nt" 1 (default) = non-temporal store of the result,
+ *   "spmv_ell_map" 1 (default) = row blocks dealt to the XCDs by their position inside the far band's period
  *   "spmv_irr"     1 (default) = two-phase kernel when the longest row exceeds 32 entries
  *   "spmv_variant" 4 (default) | 5 | 2, "spmv_grid", "spmv_irr_grid", "spmv_irr_len", "spmv_map" 0|1:
  *                  tuning knobs kept for A/B measurements (tools/spmv_ab.py) */
@@ -140,6 +145,10 @@ int its_last_region_ms(its_handle *h, float *ms);
 /* average duration (ms) of the SpMV launch INSIDE the last its_iterate_n CG region (HIP event
  * pairs around each of the first 256 launches, on the handle's stream) */
 int its_last_spmv_ms(its_handle *h, float *ms);
+/* which kernel family a whole-matrix exact SpMV (with_dot = 1: the CG form) of this matrix runs on — "spmv_ell_kernel",
+ * "spmv_stream4_kernel", "spmv_stream2_kernel", "spmv_stream5_kernel", "spmv_irr_kernel" — and the bytes one launch
+ * is asked to stream in that kernel's storage form (matrix arrays + x once + y once) */
+int its_spmv_kernel_info(its_handle *h, int which, int with_dot, char *name, int cap, int64_t *streamed_bytes);
 /* plan facts: lanes per row chosen, SELL occupancy (nnz / stored elements), row-block count */
 int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occupancy,
                   int *n_row_blocks);

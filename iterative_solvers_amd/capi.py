@@ -57,6 +57,7 @@ SIGNATURES = {
     "its_spmv_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "its_last_region_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "its_last_spmv_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "its_spmv_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, _c_i64_p]),
     "its_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_int_p, _c_dbl_p, _c_int_p]),
     "its_multicolor_order": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _c_int_p]),
     "its_permute_crs": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -218,6 +219,12 @@ class Handle:
         ms = C.c_float()
         self.check(self.L.its_last_spmv_ms(self.h, C.byref(ms)), "its_last_spmv_ms")
         return ms.value
+
+    def spmv_kernel_info(self, which=MAT_A, with_dot=False):
+        """(kernel family name, bytes one launch streams) of the exact SpMV of this matrix."""
+        buf = C.create_string_buffer(64); sb = C.c_int64()
+        self.check(self.L.its_spmv_kernel_info(self.h, which, int(with_dot), buf, 64, C.byref(sb)), "its_spmv_kernel_info")
+        return buf.value.decode(), sb.value
 
     def plan_info(self, which=MAT_A, fmt=FMT_CSR_EXACT):
         lpr, occ, nb = C.c_int(), C.c_double(), C.c_int()

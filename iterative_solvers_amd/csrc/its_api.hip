@@ -17,6 +17,7 @@ static void free_csr(CsrDev &A)
 {
     dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc); dfree(A.blk_desc_big);
     dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict); dfree(A.vidx); dfree(A.val_dict);
+    dfree(A.ell_val); dfree(A.ell_idx);
     A = CsrDev();
 }
 
@@ -296,6 +297,26 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
                     ++A.n_upper; A.upper_col_sum += col[k]; A.upper_val_xor ^= bits * 0x9E3779B97F4A7C15ull + (uint64_t)col[k];
                 }
     if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; }
+    // sliced ELL image for short regular rows (its_ell.hip), built on the device from the arrays just uploaded
+    if (A.n_off >= 1 && A.n_off <= ELL_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELL_MAX_W && n_rows > 0 &&
+        getenv("ITS_NO_ELL") == nullptr) {
+        const int64_t n_blk = ((int64_t)n_rows + ELL_RB - 1) / ELL_RB;
+        const int64_t stored = n_blk * ELL_RB * A.max_row_len;
+        if (stored <= nnz + nnz / 4 + 8 * ELL_RB && stored < ((int64_t)1 << 40)) {
+            A.ell_w = A.max_row_len; A.ell_blocks = (int)n_blk;
+            int far = 0;
+            {
+                std::vector<int> dict(256);
+                HIPCHK(h, hipMemcpy(dict.data(), A.off_dict, 256 * sizeof(int), hipMemcpyDeviceToHost));
+                for (int i = 0; i < A.n_off; ++i) far = std::max(far, std::abs(dict[i]));
+            }
+            A.ell_pb = far / ELL_RB >= 8 ? far / ELL_RB : 0;
+            if (dalloc(h, &A.ell_val, (size_t)stored) || dalloc(h, &A.ell_idx, (size_t)n_blk * ELL_RB)) return ITS_EHIP;
+            launch_ell_build(A, h->stream);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+    }
     h->have[which] = true;
     if (which == ITS_MAT_A) { h->fmt = format; h->setup_done = false; h->residual_done = false; }
     return ITS_OK;
@@ -337,7 +358,8 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         return ITS_OK;
     }
     {
-        const int rc = spmv_tune(name, value);      // process-wide launch tunables of the exact SpMV
+        int rc = spmv_tune(name, value);            // process-wide launch tunables of the exact SpMV
+        if (rc == -2) rc = ell_tune(name, value);
         if (rc == 0) return ITS_OK;
         if (rc == -1) FAIL(h, ITS_EINVAL, std::string("bad value for option ") + name);
     }
@@ -1090,6 +1112,17 @@ extern "C" int its_spmv_timed(its_handle *h, int which, const double *x_dev, dou
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_region_ms = ms;
     *avg_ms = ms / reps;
+    return ITS_OK;
+}
+
+extern "C" int its_spmv_kernel_info(its_handle *h, int which, int with_dot, char *name, int cap, int64_t *streamed_bytes)
+{
+    if (!h || which < 0 || which > 2 || !name || cap < 1) return ITS_EINVAL;
+    if (!h->have[which]) FAIL(h, ITS_ESTATE, "matrix not uploaded");
+    SpmvArgs a; a.x = h->D; a.y = h->D;                       // any 16-byte aligned pointers: only alignment is looked at
+    if (with_dot) a.dotv = h->D;
+    const char *nm = spmv_exact_kernel_name(h->mat[which], a, EPI_STORE, streamed_bytes);
+    snprintf(name, (size_t)cap, "%s", nm);
     return ITS_OK;
 }
 

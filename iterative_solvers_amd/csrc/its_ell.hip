@@ -1,0 +1,232 @@
+// its_ell.hip — the exact SpMV for short regular rows on a sliced, UNSORTED ELL image of the CRS matrix.
+//
+// Eligible (checked at upload, its_api.hip): longest row <= 8 entries, at most 15 distinct values of col - row
+// (every 5-/7-point stencil, also after the halo renumbering of a row-block partition), little padding.
+// Layout: slices of ELL_S = 128 rows; entry k (CRS order) of row j of slice s sits at
+//     ell_val[(s*W + k)*128 + j],        W = longest row of the matrix,
+// and one 32-bit word per row holds W 4-bit dictionary indices of col - row (nibble k = entry k, 0xF = no entry).
+// A lane owns two adjacent rows and runs, for each, the in-order fused multiply-add chain from 0.0 of
+// spmv_crs_cpu (kernels.hpp:380-409) — the same operations in the same order, so results are bit-identical to the
+// CRS kernels — but every load is a fully coalesced 16-byte-per-lane wave access straight from HBM: no row_ptr
+// stream, no LDS staging, no barrier.  Streamed bytes per row of a 7-pt matrix: 56 (values) + 4 (index word)
+// + 8 (x) + 8 (y) = 76, against 84 + 4 + 16 = 104 of the CRS form and 63 + 4 + 16 = 83 of the
+// 1-byte offset stream of spmv_stream4_kernel.
+//
+// Work map.  A workgroup trip is one row block of 512 rows (4 slices, one per wave); the grid is persistent
+// (2 workgroups per CU measured best on MI355X: 512 -> 0.226 ms, 768 -> 0.245, 1024 -> 0.262, 2048 -> 0.266 ms on the
+// 256^3 7-pt matrix, tools/elllab.hip).  With a dictionary whose largest |col - row| spans B >= 8 row blocks (the
+// z-plane of a 3-D stencil) the blocks are dealt to the 8 XCDs by their position inside that period: XCD e owns
+// the e-th eighth of EVERY period, so the far planes it gathers x from are the ones it has just streamed or streams
+// next, and its 4 MB L2 holds them (a contiguous eighth per XCD re-fetches x through L2 three times: 1.17x
+// over-fetch in the round-1 PMC record).  Otherwise XCD e owns the e-th contiguous eighth of the row blocks.
+#include "its_kernels.h"
+#include "its_epilogue.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace its {
+
+typedef double ell_v2d __attribute__((ext_vector_type(2)));
+
+template <int W, int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_ell_kernel(
+    int n_rows, int n_blocks, int pb, const double *__restrict__ val, const uint32_t *__restrict__ idx,
+    const int *__restrict__ dict, int nt_store, SpmvArgs a)
+{
+    __shared__ int s_dict[16];
+    __shared__ double s_red[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t < 16) s_dict[t] = t < 15 ? dict[t] : 0;
+    __syncthreads();
+    const int G = gridDim.x;
+    const int e = blockIdx.x & 7, j = blockIdx.x >> 3;
+    // list of row blocks of XCD e: position q <-> block (q / len) * per + b0 + q % len
+    int b0, len, per, q_end;
+    if (pb >= 8) {
+        b0 = (int)(((int64_t)e * pb) / 8);
+        len = (int)(((int64_t)(e + 1) * pb) / 8) - b0;
+        per = pb;
+        q_end = ((n_blocks + pb - 1) / pb) * len;
+    } else {
+        b0 = (int)(((int64_t)e * n_blocks) / 8);
+        len = (int)(((int64_t)(e + 1) * n_blocks) / 8) - b0;
+        per = 0;
+        q_end = len;
+    }
+    double lane_sum = 0.0, lane_max = 0.0;
+    for (int q = j; q < q_end; q += G >> 3) {
+        const int blk = (q / len) * per + b0 + q % len;
+        if (blk >= n_blocks) continue;
+        const int sl = blk * 4 + w;
+        const int row0 = sl * ELL_S + lane * 2;
+        const bool any = row0 < n_rows, full = row0 + 1 < n_rows;
+        // index words first: the gathers depend on them, the values are only needed by the chain
+        const uint2 iw2 = *reinterpret_cast<const uint2 *>(idx + row0);
+        const uint32_t iw[2] = {iw2.x, iw2.y};
+        const double *vp = val + (size_t)sl * W * ELL_S + lane * 2;
+        double v[W][2];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const ell_v2d q2 = *reinterpret_cast<const ell_v2d *>(vp + (size_t)k * ELL_S);
+            v[k][0] = q2.x; v[k][1] = q2.y;
+        }
+        // per-row operands of the epilogue (two adjacent rows: one 16-byte load each when both rows exist)
+        double e0[2] = {0.0, 0.0}, e1[2] = {0.0, 0.0}, e2[2] = {0.0, 0.0};
+#define ELL_LD2(dst, ptr)                                                                 \
+        do {                                                                              \
+            if (full) { const ell_v2d o2 = *reinterpret_cast<const ell_v2d *>((ptr) + row0); dst[0] = o2.x; dst[1] = o2.y; } \
+            else if (any) dst[0] = (ptr)[row0];                                           \
+        } while (0)
+        if (EPI == EPI_STORE && DOT) ELL_LD2(e0, a.dotv);
+        if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) ELL_LD2(e0, a.b);
+        if (EPI == EPI_JACOBI_SHIPPED) { ELL_LD2(e0, a.D); ELL_LD2(e1, a.x); ELL_LD2(e2, a.b); }
+#undef ELL_LD2
+        int c[W][2];
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t nib = (iw[r] >> (4 * k)) & 15u;
+                c[k][r] = nib == 15u ? 0 : row0 + r + s_dict[nib];        // no entry: gather x[0], never used
+            }
+        double xv[W][2];
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) xv[k][r] = a.x[c[k][r]];
+        double outv[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            double acc = 0.0, acc2 = 0.0, diag = 0.0;
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+                if (((iw[r] >> (4 * k)) & 15u) != 15u) chain_step<EPI>(c[k][r], row0 + r, v[k][r], xv[k][r], acc, acc2, diag);
+            outv[r] = 0.0;
+            if (r == 0 ? any : full) outv[r] = row_finish<EPI, DOT>(acc, acc2, diag, e0[r], e1[r], e2[r], lane_sum, lane_max);
+        }
+        if (a.y) {                                              // y == nullptr: only the norm is wanted
+            if (full) {
+                ell_v2d o2; o2.x = outv[0]; o2.y = outv[1];
+                if (nt_store) __builtin_nontemporal_store(o2, reinterpret_cast<ell_v2d *>(a.y + row0));
+                else *reinterpret_cast<ell_v2d *>(a.y + row0) = o2;
+            } else if (any) a.y[row0] = outv[0];
+        }
+    }
+    if (DOT || EpiKind<EPI>::norm) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) {
+            a.part_sum[blockIdx.x] = bs;
+            for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
+        }
+        if (EpiKind<EPI>::norm && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) {
+                a.part_max[blockIdx.x] = bm;
+                for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_max[z] = 0.0;
+            }
+        }
+    }
+}
+
+// ELL image from the device-resident CRS arrays: one lane per (padded) row
+__global__ __launch_bounds__(ITS_BLOCK) void ell_build_kernel(
+    int n_rows, int n_pad, int W, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+    const int *__restrict__ dict, int n_off, double *__restrict__ ell_val, uint32_t *__restrict__ ell_idx)
+{
+    __shared__ int s_dict[16];
+    if (threadIdx.x < 16) s_dict[threadIdx.x] = threadIdx.x < n_off ? dict[threadIdx.x] : 0;
+    __syncthreads();
+    const int row = blockIdx.x * ITS_BLOCK + threadIdx.x;
+    if (row >= n_pad) return;
+    const int s = row / ELL_S, jr = row % ELL_S;
+    int j0 = 0, len = 0;
+    if (row < n_rows) { j0 = rp[row]; len = rp[row + 1] - j0; }
+    uint32_t wd = 0xffffffffu;
+    for (int k = 0; k < W; ++k) {
+        double v = 0.0;
+        if (k < len) {
+            v = val[j0 + k];
+            const int off = col[j0 + k] - row;
+            uint32_t d = 0;
+            while (d + 1 < (uint32_t)n_off && s_dict[d] != off) ++d;
+            wd = (wd & ~(15u << (4 * k))) | (d << (4 * k));
+        }
+        ell_val[((size_t)s * W + k) * ELL_S + jr] = v;
+    }
+    ell_idx[row] = wd;
+}
+
+void launch_ell_build(const CsrDev &A, hipStream_t s)
+{
+    const int n_pad = A.ell_blocks * ELL_RB;
+    hipLaunchKernelGGL(ell_build_kernel, dim3((n_pad + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, s, A.n_rows, n_pad,
+                       A.ell_w, A.row_ptr, A.col, A.val, A.off_dict, A.n_off, A.ell_val, A.ell_idx);
+}
+
+static int ell_env(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static int g_ell_on = ell_env("ITS_SPMV_ELL", 1);
+static int g_ell_grid = ell_env("ITS_SPMV_ELL_GRID", 512);
+static int g_ell_nt = ell_env("ITS_SPMV_ELL_NT", 1);
+static int g_ell_map = ell_env("ITS_SPMV_ELL_MAP", 1);       // 0 = contiguous eighth per XCD even for far-banded matrices
+
+int ell_tune(const char *name, int value)
+{
+    if (!strcmp(name, "spmv_ell")) { if (value < 0 || value > 1) return -1; g_ell_on = value; return 0; }
+    if (!strcmp(name, "spmv_ell_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_ell_grid = value; return 0; }
+    if (!strcmp(name, "spmv_ell_nt")) { if (value < 0 || value > 1) return -1; g_ell_nt = value; return 0; }
+    if (!strcmp(name, "spmv_ell_map")) { if (value < 0 || value > 1) return -1; g_ell_map = value; return 0; }
+    return -2;
+}
+
+static inline bool al16p(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool spmv_ell_eligible(const CsrDev &A, const SpmvArgs &a, int epi)
+{
+    if (!g_ell_on || !A.ell_val || epi == EPI_SWEEP || spmv_valdict_selected(A)) return false;
+    // two rows per lane move as 16-byte accesses: every per-row vector must be 16-byte aligned (solver vectors are)
+    return al16p(a.y) && al16p(a.b) && al16p(a.D) && al16p(a.dotv) && (epi != EPI_JACOBI_SHIPPED || al16p(a.x));
+}
+
+template <int W>
+static void launch_ell_w(const CsrDev &A, const SpmvArgs &a, int epi, int grid, int pb, int nt, hipStream_t s)
+{
+    dim3 g(grid), b(ITS_BLOCK);
+#define ITS_LAUNCHE(E, D) \
+    hipLaunchKernelGGL((spmv_ell_kernel<W, E, D>), g, b, 0, s, A.n_rows, A.ell_blocks, pb, A.ell_val, A.ell_idx, A.off_dict, nt, a)
+    switch (epi) {
+    case EPI_STORE: if (a.dotv) ITS_LAUNCHE(EPI_STORE, true); else ITS_LAUNCHE(EPI_STORE, false); break;
+    case EPI_RESIDUAL: ITS_LAUNCHE(EPI_RESIDUAL, false); break;
+    case EPI_JACOBI_SHIPPED: ITS_LAUNCHE(EPI_JACOBI_SHIPPED, false); break;
+    case EPI_JACOBI_REF: ITS_LAUNCHE(EPI_JACOBI_REF, false); break;
+    case EPI_GS_RHS: ITS_LAUNCHE(EPI_GS_RHS, false); break;
+    case EPI_JACOBI_FUSED: ITS_LAUNCHE(EPI_JACOBI_FUSED, false); break;
+    case EPI_GS_FUSED: ITS_LAUNCHE(EPI_GS_FUSED, false); break;
+    default: break;
+    }
+#undef ITS_LAUNCHE
+}
+
+void launch_spmv_ell(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
+{
+    SpmvArgs a = a_in;
+    a.part_accum = 0;
+    int grid = g_ell_grid;
+    // small matrices: no more workgroups than row blocks (multiple of 8: the XCD map)
+    const int need = ((A.ell_blocks + 7) / 8) * 8;
+    if (grid > need) grid = need < 8 ? 8 : need;
+    const int pb = g_ell_map ? A.ell_pb : 0;
+    // the result of a CG / Jacobi product is read by the very next kernel: plain store; non-temporal otherwise
+    const int nt = g_ell_nt;
+    switch (A.ell_w) {
+    case 1: launch_ell_w<1>(A, a, epi, grid, pb, nt, s); break;
+    case 2: launch_ell_w<2>(A, a, epi, grid, pb, nt, s); break;
+    case 3: launch_ell_w<3>(A, a, epi, grid, pb, nt, s); break;
+    case 4: launch_ell_w<4>(A, a, epi, grid, pb, nt, s); break;
+    case 5: launch_ell_w<5>(A, a, epi, grid, pb, nt, s); break;
+    case 6: launch_ell_w<6>(A, a, epi, grid, pb, nt, s); break;
+    case 7: launch_ell_w<7>(A, a, epi, grid, pb, nt, s); break;
+    default: launch_ell_w<8>(A, a, epi, grid, pb, nt, s); break;
+    }
+}
+
+}  // namespace its

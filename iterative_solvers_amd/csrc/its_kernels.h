@@ -22,6 +22,13 @@ constexpr int IRR_ROW_LEN = 32;           // longest row above which the exact S
 // loads are unconditional (2 slices x 1024 entries past an aligned block start)
 constexpr int CSR_PAD = 2048 + 16;
 
+// sliced unsorted ELL image of matrices with short regular rows (its_ell.hip): slices of ELL_S rows, a workgroup
+// trip covers ELL_RB rows
+constexpr int ELL_S = 128;
+constexpr int ELL_RB = 4 * ELL_S;
+constexpr int ELL_MAX_W = 8;              // longest row an ELL image is built for (8 nibbles in the index word)
+constexpr int ELL_MAX_OFF = 15;           // dictionary entries a nibble can name (0xF = no entry)
+
 enum SpmvEpilogue {
     EPI_STORE = 0,        // y = A x                                  (kernels.hpp:380-409)
     EPI_RESIDUAL = 1,     // y = b - A x, + sum r^2 and max|r|        (kernels.hpp:670-726)
@@ -53,6 +60,13 @@ struct CsrDev {
     unsigned char *vidx = nullptr;
     double *val_dict = nullptr;               // [256]
     int n_vals = 0;                           // 0 = not eligible
+    // sliced ELL image (its_ell.hip), built at upload when the matrix is eligible: longest row <= ELL_MAX_W,
+    // n_off <= ELL_MAX_OFF, padding below 25 %.  ell_val[(slice*ell_w + k)*ELL_S + row_in_slice], ell_idx[row] =
+    // ell_w nibbles (dictionary index of entry k, 0xF = none); ell_pb = row blocks per period of the far band
+    // (0 = no period map)
+    double *ell_val = nullptr;
+    uint32_t *ell_idx = nullptr;
+    int ell_w = 0, ell_blocks = 0, ell_pb = 0;
     // stream plan
     int n_blocks = 0;
     int4 *blk_desc = nullptr;                 // {first row, rows, first nnz, end nnz} per row block
@@ -97,6 +111,13 @@ void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const
 // true when this launch would walk CsrDev::blk_desc_big (callers that pass descriptor lists of their own must
 // derive them from the matching plan: only spmv_stream4_kernel has room for the larger blocks)
 bool spmv_exact_takes_big_plan(const CsrDev &A, const SpmvArgs &a, int epilogue);
+const char *spmv_exact_kernel_name(const CsrDev &A, const SpmvArgs &a, int epilogue, int64_t *streamed_bytes);
+// sliced-ELL form of the exact SpMV (its_ell.hip): whole-matrix launches of eligible matrices
+bool spmv_valdict_selected(const CsrDev &A);            // option "spmv_valdict" applies to this matrix
+bool spmv_ell_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);
+void launch_spmv_ell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
+void launch_ell_build(const CsrDev &A, hipStream_t s);   // fills ell_val / ell_idx from the device CRS arrays
+int ell_tune(const char *name, int value);               // "spmv_ell", "spmv_ell_grid", "spmv_ell_nt", "spmv_ell_map"
 void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 

@@ -2,6 +2,7 @@
 // All kernels: 256-thread workgroups (4 wavefronts of 64), persistent grids walking their share of the
 // work (2-5 workgroups per CU for the SpMV pipelines, ITS_NPART for the vector kernels); HBM-bound, no MFMA.
 #include "its_kernels.h"
+#include "its_epilogue.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -35,9 +36,6 @@ constexpr int S2_CAP = SPMV_NNZ_MAX + 8;
 // non-temporal hint on the col/val/row_ptr stream of spmv_stream4_kernel: measured a LOSS inside the CG loop
 // (2104 vs 2123 it/s), although those bytes are read once — kept as a switch for re-measurement
 constexpr int SPMV4_NT = 0;
-// the sweep reads its right-hand side and the diagonal once per trip, for the last time: non-temporal (multicolour GS
-// trip at 256^3 0.551 -> 0.546 ms)
-constexpr bool SWEEP_NT = true;
 static_assert(SPMV_NNZ_MAX + 3 <= 2 * 4 * ITS_BLOCK, "staging is written for two slices of 4 entries per lane");
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -58,82 +56,6 @@ template <int NT> __device__ __forceinline__ int ld_i1(const int *p) { return NT
 template <int NT> __device__ __forceinline__ void st_d1(double *p, double v)
 {
     if (NT & 2) __builtin_nontemporal_store(v, p); else *p = v;
-}
-
-// --------------------------------------------------------------------------------------
-// What the epilogues ask of the per-row walk, shared by every exact kernel below.
-//   chain_step   one entry of the row, in CRS order: `acc` is the epilogue's own chain (all entries; all but the
-//                diagonal for the Jacobi forms, jacobi.hpp:76-85; entries right of the diagonal for EPI_GS_FUSED),
-//                `acc2` the full chain of the fused forms (the recorded residual of the same x)
-//   row_finish   the value to store and the row's contribution to the partial sums
-// e0..e2 are the epilogue's per-row operands (epi_operands), loaded where the kernel's pipeline wants them.
-// --------------------------------------------------------------------------------------
-template <int EPI> struct EpiKind {
-    static constexpr bool skip_diag = EPI == EPI_JACOBI_REF || EPI == EPI_JACOBI_FUSED;
-    static constexpr bool upper_only = EPI == EPI_GS_FUSED;
-    static constexpr bool fused = EPI == EPI_JACOBI_FUSED || EPI == EPI_GS_FUSED;
-    static constexpr bool norm = EPI == EPI_RESIDUAL || fused;          // writes r^2 / max|r| partials
-    static constexpr bool needs_col = skip_diag || upper_only;
-};
-
-template <int EPI>
-__device__ __forceinline__ void chain_step(int c, int row, double v, double x, double &acc, double &acc2, double &diag)
-{
-    // An entry the chain leaves out enters it as fma(0, 0, acc) instead of a select on acc: acc starts at +0.0
-    // and round-to-nearest never makes it -0.0, so acc + (+0.0) returns acc bit for bit, and the selects sit on
-    // the operands, off the dependent chain (a select per entry on acc itself made the EPI_GS_FUSED walk of a
-    // long row 1.4x slower).
-    if (EpiKind<EPI>::fused) acc2 = fma(v, x, acc2);
-    if (EpiKind<EPI>::skip_diag) {
-        const bool dg = c == row;
-        diag = dg ? v : diag;
-        acc = fma(dg ? 0.0 : v, dg ? 0.0 : x, acc);
-    } else if (EpiKind<EPI>::upper_only) {
-        const bool up = c > row;
-        acc = fma(up ? v : 0.0, up ? x : 0.0, acc);
-    } else {
-        acc = fma(v, x, acc);
-    }
-}
-
-template <int EPI, bool DOT>
-__device__ __forceinline__ void epi_operands(const SpmvArgs &a, int row, double &e0, double &e1, double &e2)
-{
-    if (EPI == EPI_STORE && DOT) e0 = a.dotv[row];
-    if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused)
-        e0 = a.b[row];
-    if (EPI == EPI_JACOBI_SHIPPED) { e0 = a.D[row]; e1 = a.x[row]; e2 = a.b[row]; }
-    if (EPI == EPI_SWEEP) { e0 = SWEEP_NT ? __builtin_nontemporal_load(a.b + row) : a.b[row]; e1 = SWEEP_NT ? __builtin_nontemporal_load(a.D + row) : a.D[row]; }
-}
-
-template <int EPI, bool DOT>
-__device__ __forceinline__ double row_finish(double acc, double acc2, double diag, double e0, double e1, double e2,
-                                             double &lane_sum, double &lane_max)
-{
-    double outv;
-    if (EPI == EPI_STORE) {
-        outv = acc;
-        if (DOT) lane_sum = fma(acc, e0, lane_sum);
-    } else if (EPI == EPI_RESIDUAL) {
-        outv = e0 - acc;
-        lane_sum = fma(outv, outv, lane_sum);
-        lane_max = fmax(lane_max, fabs(outv));
-    } else if (EPI == EPI_JACOBI_SHIPPED) {
-        const double adj = fma(-e0, acc, e1);
-        outv = (e2 - adj) / e0;
-    } else if (EPI == EPI_JACOBI_REF || EPI == EPI_JACOBI_FUSED) {
-        outv = (e0 - acc) / diag;
-    } else if (EPI == EPI_SWEEP) {
-        outv = (e0 - acc) / e1;
-    } else {                                        // EPI_GS_RHS, EPI_GS_FUSED
-        outv = fma(-1.0, acc, e0);
-    }
-    if (EpiKind<EPI>::fused) {
-        const double r = e0 - acc2;
-        lane_sum = fma(r, r, lane_sum);
-        lane_max = fmax(lane_max, fabs(r));
-    }
-    return outv;
 }
 
 // IDX != 0: stream the 1-byte column-offset dictionary index instead of col (see spmv_stream4_kernel, CMP = 1)
@@ -864,6 +786,8 @@ static int g_spmv_irr = env_int("ITS_SPMV_IRR", 1);             // 0 = never use
 static int g_spmv_irr_grid = env_int("ITS_SPMV_IRR_GRID", 1280);
 static int g_spmv_irr_len = env_int("ITS_SPMV_IRR_LEN", IRR_ROW_LEN);   // longest row above which it is used
 static int g_spmv_bigplan = env_int("ITS_SPMV_BIGPLAN", 1);     // 0 = spmv_stream4_kernel on the ordinary plan too
+// the opt-in value-dictionary stream (2 bytes per nonzero) moves fewer bytes than the ELL image: it keeps its kernel
+bool spmv_valdict_selected(const CsrDev &A) { return g_spmv_valdict && g_spmv_idx && A.n_off > 0 && A.n_vals > 0 && A.max_row_len <= 8; }
 int spmv_tune(const char *name, int value)
 {
     if (!strcmp(name, "spmv_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_grid = value; return 0; }
@@ -986,8 +910,27 @@ bool spmv_exact_takes_big_plan(const CsrDev &A, const SpmvArgs &a, int epi)
     return cmp == 1;                                             // spmv_stream2_kernel<.., IDX = 2>
 }
 
+// which kernel family a whole-matrix launch of the exact SpMV takes (same tests as the dispatch), and the bytes
+// it is asked to stream per launch (matrix arrays in the form that kernel reads + x once + y once)
+const char *spmv_exact_kernel_name(const CsrDev &A, const SpmvArgs &a, int epi, int64_t *streamed)
+{
+    const int64_t n = A.n_rows, nnz = A.nnz;
+    const int cmp = (A.n_off > 0 && g_spmv_idx) ? ((A.n_vals > 0 && g_spmv_valdict) ? 2 : 1) : 0;
+    const int64_t csr = (cmp == 2 ? 2 : cmp == 1 ? 9 : 12) * nnz + 4 * (n + 1) + 16 * n;
+    if (streamed) *streamed = csr;
+    if (spmv_ell_eligible(A, a, epi)) {
+        if (streamed) *streamed = (int64_t)A.ell_blocks * ELL_RB * (8 * A.ell_w + 4) + 16 * n;
+        return "spmv_ell_kernel";
+    }
+    if (A.max_row_len > g_spmv_irr_len && g_spmv_irr) { if (streamed) *streamed = 12 * nnz + 4 * (n + 1) + 16 * n; return "spmv_irr_kernel"; }
+    if (A.max_row_len <= 8 && (g_spmv_variant == 5 || (g_spmv_variant == 4 && cmp == 2))) return "spmv_stream5_kernel";
+    if (g_spmv_variant == 4 && A.max_row_len <= 8 && epi == EPI_STORE && a.dotv) return "spmv_stream4_kernel";
+    return "spmv_stream2_kernel";
+}
+
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
 {
+    if (spmv_ell_eligible(A, a_in, epi)) { launch_spmv_ell(A, a_in, epi, s); return; }
     if (spmv_exact_takes_big_plan(A, a_in, epi)) launch_spmv_exact_desc(A, A.blk_desc_big, A.n_blocks_big, a_in, epi, 0, s);
     else launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s);
 }

@@ -16,6 +16,8 @@ python3 - "$R" <<'PY'
 import csv, glob, collections, sys
 R=sys.argv[1]
 out=open(f'gpurun_out/{R}/pmc_summary.txt','w')
+import subprocess
+print('# kernel_sources_sha256=' + subprocess.check_output(['python3','bench.py','--print-source-hash'], text=True).strip(), file=out)
 for cname in ('FETCH_SIZE','WRITE_SIZE'):
     for f in glob.glob(f'gpurun_out/{R}/pmc_{cname}/*/*counter_collection.csv'):
         acc=collections.defaultdict(list)
