@@ -117,6 +117,14 @@ int its_final_residual(its_handle *h, double *residual_norm);
 int its_spmv(its_handle *h, int which, const double *x, double *y, int where, int format);
 /* Device-pointer BLAS-1 with deterministic fixed-order reductions.  Result to *out (host). */
 int its_dot(its_handle *h, const double *a_dev, const double *b_dev, int64_t n, double *out);      /* kernels.hpp:170-183 */
+/* its_dot for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  Calls no hipMalloc / hipFree / allocating routine and does not
+ * synchronise: the ITS_NPART partial sums go to a static 16 KB device array that every GPU the library runs on holds
+ * until the process ends, the result (bit-identical to its_dot's) to *out_dev (device memory of the caller) in
+ * stream order on the handle's stream — read it after its_synchronize.  n <= ITS_NOALLOC_MAX_N, else ITS_EINVAL.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two handles, two threads) race. */
+#define ITS_NOALLOC_MAX_N ((int64_t)1 << 33)
+int its_dot_noalloc(its_handle *h, const double *a_dev, const double *b_dev, int64_t n, double *out_dev);
 int its_nrm2(its_handle *h, const double *v_dev, int64_t n, double *out);                          /* kernels.hpp:542-556 */
 int its_norm_inf(its_handle *h, const double *v_dev, int64_t n, double *out);                      /* kernels.hpp:558-575 */
 int its_axpby(its_handle *h, double *out_dev, const double *a_dev, const double *b_dev,

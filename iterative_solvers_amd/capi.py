@@ -44,6 +44,7 @@ SIGNATURES = {
     "its_final_residual": (C.c_int, [C.c_void_p, _c_dbl_p]),
     "its_spmv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "its_dot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _c_dbl_p]),
+    "its_dot_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "its_nrm2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _c_dbl_p]),
     "its_norm_inf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _c_dbl_p]),
     "its_axpby": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double]),

@@ -22,6 +22,15 @@ static void free_csr(CsrDev &A)
 }
 
 // ---------------------------------------------------------------------------------------
+// Scratch of the entry point that allocates nothing (its_dot_noalloc, below): the ITS_NPART per-workgroup partial
+// sums of one reduction, 16 KB per GPU, held from module load until the process ends.  `scratch` is a host-side
+// stand-in for the symbol, NOT a device address: host code only ever uses the per-device address that
+// its_create() obtains with hipGetSymbolAddress (each GPU has its own copy of the array at its own address).
+static __device__ __align__(256) double scratch[ITS_NPART];
+constexpr int ITS_MAX_DEVICES = 64;
+static double *g_scratch_ptr[ITS_MAX_DEVICES] = {};
+
+// ---------------------------------------------------------------------------------------
 extern "C" const char *its_version(void) { return "its_hip 0.1 (gfx950)"; }
 extern "C" const char *its_last_error(const its_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -34,6 +43,12 @@ extern "C" int its_create(its_handle **out, int device)
     if (const char *e = getenv("ITS_DIST_OVERLAP")) h->dist_overlap = atoi(e) != 0;
     if (device >= 0) { if (hipSetDevice(device) != hipSuccess) { delete h; return ITS_EHIP; } }
     (void)hipGetDevice(&h->device);
+    // once per device, with that device current: the address of THIS device's copy of the no-allocation scratch
+    if (h->device >= 0 && h->device < ITS_MAX_DEVICES && !g_scratch_ptr[h->device]) {
+        double *ptr = nullptr;
+        if (hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) { delete h; return ITS_EHIP; }
+        g_scratch_ptr[h->device] = ptr;
+    }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ITS_EHIP; }
     (void)hipEventCreate(&h->ev0); (void)hipEventCreate(&h->ev1);
     for (int i = 0; i < 4; ++i) {
@@ -1156,6 +1171,26 @@ extern "C" int its_dot(its_handle *h, const double *a, const double *b, int64_t 
     launch_dot_partials(a, b, n, h->part[2], h->stream);
     launch_reduce_finalize(h->part[2], h->sc + SC_TMP, FIN_SUM, h->stream);
     return scalar_out(h, out);
+}
+
+// its_dot without any allocation and without a host round trip: the partial sums go to this GPU's static scratch
+// array (through the address taken at its_create, never through the symbol's name), the result to caller memory on
+// the device.  Same two kernels, same fixed order as its_dot: bit-identical value.  Stream-ordered, no
+// synchronisation: the value is in out_dev once the handle's stream has reached this point (its_synchronize).
+extern "C" int its_dot_noalloc(its_handle *h, const double *a_dev, const double *b_dev, int64_t n, double *out_dev)
+{
+    if (!h || !a_dev || !b_dev || !out_dev || n < 0) return ITS_EINVAL;
+    if (n > ITS_NOALLOC_MAX_N) FAIL(h, ITS_EINVAL, "its_dot_noalloc: n exceeds ITS_NOALLOC_MAX_N (2^33 elements)");
+    if (h->device < 0 || h->device >= ITS_MAX_DEVICES || !g_scratch_ptr[h->device])
+        FAIL(h, ITS_ESTATE, "its_dot_noalloc: no scratch address for this handle's device");
+    HIPCHK(h, hipSetDevice(h->device));
+    double *part = g_scratch_ptr[h->device];
+    // every launch rewrites all ITS_NPART slots (its own partials, zeros in the slots a smaller grid leaves
+    // unowned: store_partial), so nothing of an earlier, larger call survives
+    launch_dot_partials(a_dev, b_dev, n, part, h->stream);
+    launch_reduce_finalize(part, out_dev, FIN_SUM, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return ITS_OK;
 }
 
 extern "C" int its_nrm2(its_handle *h, const double *v, int64_t n, double *out)
