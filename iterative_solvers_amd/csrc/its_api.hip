@@ -4,6 +4,7 @@
 #include "its_handle.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -12,6 +13,12 @@
 #include <numeric>
 #include <string>
 #include <vector>
+
+// 0 = watch the pinned word (default), 1 = write the word the same way but wait with hipStreamSynchronize
+// (ITS_READBACK_SYNC), 2 = device slot + 8-byte copy + synchronize (ITS_READBACK_COPY).  its_set_option "readback"
+// overrides the environment (tests exercise all three against each other).
+static int g_readback_mode = getenv("ITS_READBACK_COPY") ? 2 : getenv("ITS_READBACK_SYNC") ? 1 : 0;
+static inline int readback_mode() { return g_readback_mode; }
 
 static void free_csr(CsrDev &A)
 {
@@ -33,6 +40,21 @@ static double *g_scratch_ptr[ITS_MAX_DEVICES] = {};
 // ---------------------------------------------------------------------------------------
 extern "C" const char *its_version(void) { return "its_hip 0.1 (gfx950)"; }
 extern "C" const char *its_last_error(const its_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+// pinned read-back buffer with room for a restart length of m (its_handle.h: layout); grows, never shrinks
+static int size_pinned(its_handle *h, int m)
+{
+    const size_t region = (size_t)m + 2;
+    const size_t need = std::max<size_t>(4096, PIN_REGIONS + 3 * region);
+    if (need > h->pinned_cap) {
+        if (h->pinned) (void)hipHostFree(h->pinned);
+        h->pinned = nullptr; h->pinned_cap = 0;
+        HIPCHK(h, hipHostMalloc((void **)&h->pinned, need * sizeof(double), hipHostMallocDefault));
+        h->pinned_cap = need;
+    }
+    h->pin_copy = PIN_REGIONS; h->pin_y = PIN_REGIONS + region; h->pin_h = PIN_REGIONS + 2 * region;
+    return ITS_OK;
+}
 
 extern "C" int its_create(its_handle **out, int device)
 {
@@ -57,7 +79,7 @@ extern "C" int its_create(its_handle **out, int device)
     }
     if (dalloc(h, &h->sc, SC_COUNT) != ITS_OK) { delete h; return ITS_EHIP; }
     (void)hipMemsetAsync(h->sc, 0, SC_COUNT * sizeof(double), h->stream);
-    if (hipHostMalloc((void **)&h->pinned, 4096 * sizeof(double), hipHostMallocDefault) != hipSuccess) { delete h; return ITS_EHIP; }
+    if (size_pinned(h, 0) != ITS_OK) { delete h; return ITS_EHIP; }
     (void)hipStreamSynchronize(h->stream);
     *out = h;
     return ITS_OK;
@@ -207,12 +229,22 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) FAIL(h, ITS_EINVAL, "row_ptr[0] != 0 or row_ptr[n] != nnz");
     if (nnz > INT32_MAX - 16) FAIL(h, ITS_EUNSUPPORTED, "nnz exceeds int32 offsets (sparse_matrix.hpp:20-27)");
     HIPCHK(h, hipSetDevice(h->device));
-    CsrDev &A = h->mat[which];
-    free_csr(A);
-    A.n_rows = n_rows; A.n_cols = n_cols; A.nnz = nnz;
-    // validate what the kernels assume: monotone row_ptr, columns inside [0, n_cols)
+    // validate what the kernels assume BEFORE anything of the old matrix is given up: monotone row_ptr, columns
+    // inside [0, n_cols).  A rejected upload leaves the handle as it was.
     for (int i = 0; i < n_rows; ++i) if (row_ptr[i + 1] < row_ptr[i]) FAIL(h, ITS_EINVAL, "row_ptr not monotone");
     for (int64_t k = 0; k < nnz; ++k) if (col[k] < 0 || col[k] >= n_cols) FAIL(h, ITS_EINVAL, "column index out of range");
+    CsrDev &A = h->mat[which];
+    // from here on the old matrix is gone: whatever was derived from it goes with it, and a failure below leaves
+    // the slot empty (have[which] false), never half-built
+    h->have[which] = false;
+    h->setup_done = false; h->ahead = false;
+    if (which == ITS_MAT_A) h->residual_done = false;
+    if (which == ITS_MAT_L) {                     // the sweep schedule describes the old L
+        dfree(h->level_rows); dfree(h->sweep_desc);
+        h->n_levels = 0; h->level_ptr.clear(); h->level_nshort.clear(); h->level_desc_first.clear(); h->level_desc_count.clear();
+    }
+    free_csr(A);
+    A.n_rows = n_rows; A.n_cols = n_cols; A.nnz = nnz;
     if (dalloc(h, &A.row_ptr, (size_t)n_rows + 1) || dalloc(h, &A.col, (size_t)nnz + CSR_PAD) || dalloc(h, &A.val, (size_t)nnz + CSR_PAD))
         return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.row_ptr, row_ptr, ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
@@ -364,6 +396,16 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
     if (!strcmp(name, "sweep_stream")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_stream: 0 or 1");
         h->sweep_stream = value;
+        return ITS_OK;
+    }
+    if (!strcmp(name, "readback")) {
+        if (value < 0 || value > 2) FAIL(h, ITS_EINVAL, "readback: 0 (watch the pinned word), 1 (synchronize), 2 (copy + synchronize)");
+        g_readback_mode = value;
+        return ITS_OK;
+    }
+    if (!strcmp(name, "watch_window_ms")) {
+        if (value < 0) FAIL(h, ITS_EINVAL, "watch_window_ms >= 0");
+        h->watch_window_ms = value; h->watch_misses = 0;
         return ITS_OK;
     }
     if (!strcmp(name, "fused_residual")) {
@@ -634,7 +676,9 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         if (rc) return rc;
     } else if (solver_kind == ITS_GMRES) {                           // gmres.hpp:672-786
         if (restart_len < 1) FAIL(h, ITS_EINVAL, "restart_len < 1");
+        if (restart_len > (1 << 24)) FAIL(h, ITS_EINVAL, "restart_len beyond 2^24");
         const int m = h->m = restart_len;
+        { int rcp = size_pinned(h, m); if (rcp) return rcp; }
         dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
         if (dalloc(h, &h->V, (((size_t)ne + 31) & ~(size_t)31) * (size_t)(m + 1)) || dalloc(h, &h->hcol_dev, m + 2) || dalloc(h, &h->y_dev, m + 1)) return ITS_EHIP;
         h->Rm.assign((size_t)(m + 1) * m, 0.0); h->g.assign(m + 1, 0.0);
@@ -673,23 +717,29 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
 // ---------------------------------------------------------------------------------------
 constexpr uint64_t kPendingWord = 0x7ff8dead0badf00dull;
 static inline void arm_pinned_word(double *slot) { *reinterpret_cast<volatile uint64_t *>(slot) = kPendingWord; }
+// Returns once the watched word has been written by the trip's last kernel.  What that does and does not mean: the
+// kernels of the trip that ran BEFORE the last one are complete (stream order), and so are their writes to pinned
+// memory (the GMRES H-column entries above the watched one); OTHER workgroups of the last kernel may still be
+// running.  That is safe because the host touches nothing those workgroups write: every later access to device
+// vectors is queued on the same stream behind that kernel (its_download_x, the next trip, its_synchronize).  The
+// acquire fence orders the host's reads of the other pinned words after the read that saw the word arrive.
 static int wait_pinned_word(its_handle *h, const double *slot_d)
 {
-    static const bool use_sync = getenv("ITS_READBACK_SYNC") != nullptr;
     const volatile uint64_t *slot = reinterpret_cast<const volatile uint64_t *>(slot_d);
     bool arrived = false;
-    if (!use_sync && h->watch_misses < 2) {
+    if (g_readback_mode == 0 && h->watch_misses < 2) {
         const auto t0 = std::chrono::steady_clock::now();
         for (int spins = 0; !arrived; ++spins) {
-            arrived = *slot != kPendingWord;
+            arrived = __atomic_load_n(const_cast<const uint64_t *>(reinterpret_cast<const volatile uint64_t *>(slot)), __ATOMIC_ACQUIRE) != kPendingWord;
             if (!arrived && (spins & 1023) == 1023 &&
-                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(h->watch_window_ms)) break;
         }
-        // trips longer than the watch window, or a platform on which the word only shows up at the synchronize:
-        // after two misses this handle synchronizes straight away instead of paying the window every trip
+        // a trip longer than the watch window (huge systems, a busy GPU): after two misses this handle synchronizes
+        // straight away instead of paying the window every trip
         if (!arrived) ++h->watch_misses;
     }
     if (!arrived) HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
     return ITS_OK;
 }
 
@@ -801,10 +851,10 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     int rc = solver_spmv(h, a, EPI_STORE);                            // gmres.hpp:234
     if (rc) return rc;
     if (h->precond == ITS_PRECOND_GS) { if ((rc = sweep(h, w, w))) return rc; }   // gmres.hpp:251
-    // the Hessenberg column is written into pinned host memory when it fits there (slots 2048..), else copied
-    static const bool use_copy = getenv("ITS_READBACK_COPY") != nullptr;
-    const bool hcol_pinned = k + 2 <= 2000 && !use_copy;
-    double *hcol_out = hcol_pinned ? h->pinned + 2048 : h->hcol_dev;
+    // the Hessenberg column is written straight into pinned host memory (region pin_h, m + 2 doubles), or copied
+    const bool use_copy = readback_mode() == 2;
+    const bool hcol_pinned = !use_copy;
+    double *hcol_out = hcol_pinned ? h->pinned + h->pin_h : h->hcol_dev;
     if (hcol_pinned) arm_pinned_word(hcol_out + (k + 1));
     // MGS (gmres.hpp:269-329): step j finishes w -= h_{j-1} v_{j-1} and starts h_j = w . v_j
     const double *prev_part = nullptr; int prev_scalar = 0;
@@ -826,9 +876,9 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
         if ((rc = wait_pinned_word(h, hcol_out + (k + 1)))) return rc;
         for (int i = 0; i <= k + 1; ++i) hc[i] = hcol_out[i];
     } else {
-        HIPCHK(h, hipMemcpyAsync(h->pinned, h->hcol_dev, (size_t)(k + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pinned + h->pin_copy, h->hcol_dev, (size_t)(k + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        for (int i = 0; i <= k + 1; ++i) hc[i] = h->pinned[i];
+        for (int i = 0; i <= k + 1; ++i) hc[i] = h->pinned[h->pin_copy + i];
     }
     if (h->gmres_givens == 1) {
         // ---- the reference's formulation, product for product (gmres.hpp:427-658): J = I with
@@ -895,8 +945,8 @@ static int gmres_get_x(its_handle *h, double *x_out, const double *x0, int iter_
         y[row] = (h->g[row] - sum) / h->Rm[(size_t)row * (m + 1) + row];
     }
     const int terms = std::max(0, k + 1);
-    for (int i = 0; i < m + 1; ++i) h->pinned[1024 + i] = y[i];
-    HIPCHK(h, hipMemcpyAsync(h->y_dev, h->pinned + 1024, (size_t)(m + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int i = 0; i < m + 1; ++i) h->pinned[h->pin_y + i] = y[i];
+    HIPCHK(h, hipMemcpyAsync(h->y_dev, h->pinned + h->pin_y, (size_t)(m + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     launch_gmres_update_x(x_out, x0, h->V, (int64_t)ld, h->y_dev, terms, n, h->stream);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));   // pinned y buffer is reused
@@ -925,8 +975,8 @@ extern "C" int its_iterate(its_handle *h, int iter_count, double *residual_norm)
     // returns ~6 us earlier per trip than a stream synchronize, and at 256^3 the next trip is queued while the tail
     // of this one drains.  ITS_READBACK_COPY=1 / ITS_READBACK_SYNC=1 select the device-slot copy / the plain
     // synchronize for A/B runs.
-    static const bool use_copy = getenv("ITS_READBACK_COPY") != nullptr;
-    double *slot = h->pinned + 2000;
+    const bool use_copy = readback_mode() == 2;
+    double *slot = h->pinned + PIN_RES;
     double *res = use_copy ? h->sc + SC_RES : slot;
     if (!use_copy) arm_pinned_word(slot);
     if (h->solver == ITS_CG) rc = trip_cg(h, res);

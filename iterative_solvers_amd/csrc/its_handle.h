@@ -50,7 +50,12 @@ struct its_handle {
     double *sc = nullptr;                 // SC_COUNT device scalars
     double *res_dev = nullptr;            // per-trip residuals for its_iterate_n
     int res_cap = 0;
-    double *pinned = nullptr;             // small pinned host buffer
+    // pinned host buffer.  Layout (doubles): [0, PIN_RES) scalar read-backs, PIN_RES the per-trip residual word,
+    // then three regions of m + 2 each, sized from the GMRES restart length in its_solver_setup:
+    // pin_copy (H column, copy path), pin_y (y staging of gmres_get_x), pin_h (H column written by the kernels)
+    double *pinned = nullptr;
+    size_t pinned_cap = 0;
+    size_t pin_copy = 0, pin_y = 0, pin_h = 0;
     int rr_slot = 0;
 
     int solver = -1, precond = 0, jacobi_mode = 0, gs_order = 0;
@@ -63,6 +68,7 @@ struct its_handle {
     bool ahead = false;
     bool setup_done = false, residual_done = false;
     double last_residual = 0.0;
+    int watch_window_ms = 50;                    // option "watch_window_ms": how long its_iterate watches before it synchronizes
     int watch_misses = 0;                        // wait_pinned_word: times the watched word did not arrive within its window
     // triangular sweep schedule (levels of L; colours when the matrix was colour-permuted)
     std::vector<int> level_ptr;           // host offsets into level_rows
@@ -79,6 +85,9 @@ struct its_handle {
 
     DistPlan *dist = nullptr;
 };
+
+constexpr size_t PIN_RES = 8;             // index of the residual word inside its_handle::pinned
+constexpr size_t PIN_REGIONS = 16;        // first index of the restart-length-sized regions
 
 #define HIPCHK(h, call)                                                                     \
     do {                                                                                    \
