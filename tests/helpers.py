@@ -38,3 +38,48 @@ def rel_err(a, b):
     d = np.max(np.abs(a - b)) if a.size else 0.0
     s = np.max(np.abs(b)) if b.size else 1.0
     return d / (s if s > 0 else 1.0)
+
+
+def oracle_with_noise(orc, rp, col, val, b, x0, kind, threads=(2, 3, 4, 5, 6), **kw):
+    """The oracle at 1 thread (bit-identical to the compiled reference at OMP_NUM_THREADS=1) plus the reference's own
+    sensitivity to the ORDER of its dot-product reductions, measured by re-running it at other thread counts:
+      ref["noise"][k]       envelope of |history_t[k'] - history_1[k']| over the thread counts and k' <= k + 8
+      ref["iters_spread"]   largest |iters_t - iters_1|
+    Tests widen their bounds by multiples of these instead of by constants: the GPU may deviate from the reference
+    by no more than the reference deviates from itself when only its summation order changes."""
+    orc.set_threads(1)
+    ref = orc.solve(rp, col, val, b, x0.copy(), kind, **kw)
+    noise = np.zeros(len(ref["history"]))
+    spread = 0
+    for t in threads:
+        orc.set_threads(t)
+        alt = orc.solve(rp, col, val, b, x0.copy(), kind, **kw)
+        k = min(len(alt["history"]), len(noise))
+        noise[:k] = np.maximum(noise[:k], np.abs(alt["history"][:k] - ref["history"][:k]))
+        spread = max(spread, abs(alt["iters"] - ref["iters"]))
+    orc.set_threads(1)
+    env = np.maximum.accumulate(noise)
+    ref["noise"] = np.concatenate([env[8:], np.full(min(8, len(env)), env[-1] if len(env) else 0.0)])
+    ref["iters_spread"] = spread
+    return ref
+
+
+def mtx_path(name):
+    """Matrix Market file of a named test matrix: the committed fixture under tests/golden/ when there is one,
+    else written once (iterative_solvers_amd.matgen regenerates it bit for bit) into a per-user temp directory."""
+    import os
+    import tempfile
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".mtx")
+    if os.path.exists(g):
+        return g
+    d = os.path.join(tempfile.gettempdir(), f"its_mtx_{os.getuid()}")
+    os.makedirs(d, exist_ok=True)
+    p = os.path.join(d, name + ".mtx")
+    if not os.path.exists(p):
+        tmp = p + f".{os.getpid()}"
+        matgen.write_mtx(tmp, *ALL_MATRICES[name]())
+        os.replace(tmp, p)
+    return p
+
+
+ALL_MATRICES = dict(MATRICES, lap2d_256=lambda: matgen.laplace2d_5pt(256))

@@ -16,7 +16,14 @@ EXE = os.path.join(os.path.dirname(HERE), "iterative_solvers_amd", "host", "its_
 HIST = json.load(open(os.path.join(G, "reference_histories.json")))
 LINE = re.compile(r"\|\|A\*x_(\d+) - b\|\|_infty = (\S+)")
 
-CASES = [k for k in sorted(HIST) if k.split("|")[0] in ("lap2d_16", "lap3d_8", "cd27_6", "pl_200")]
+CASES = sorted(HIST)          # incl. lap2d_64, lap3d_16, cd27_12 and lap2d_256 = BASELINE.json configs[0]
+
+
+def _mtx(m):
+    import sys
+    sys.path.insert(0, HERE)
+    from helpers import mtx_path
+    return mtx_path(m)
 
 
 @pytest.mark.parametrize("key", CASES)
@@ -30,7 +37,7 @@ def test_cli_matches_reference_output(key):
     m, s, sc, mm, pp = key.split("|")
     restart, pre = int(mm[1:]), pp[1:]
     exp = HIST[key]
-    cmd = [EXE, os.path.join(G, m + ".mtx"), s] + (["-p", pre] if pre else ["-scale", sc])
+    cmd = [EXE, _mtx(m), s] + (["-p", pre] if pre else ["-scale", sc])
     env = dict(os.environ, ITS_GMRES_RESTART_LEN=str(restart), ITS_TOL="1e-10")
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -56,12 +63,23 @@ def test_cli_matches_reference_output(key):
         ok = np.isfinite(w) & (w < 1e100)
         r0 = stop10 / 1e-10
         bound = np.maximum(1e-10 * np.maximum(w[ok], 1e-2 * r0), 2e-15 * w[ok])
-        # restarted GMRES(10) amplifies rounding noise by ~1e7: the reference itself moves 3-4 % under a
-        # change of its reduction order (measured, see test_gpu_solvers.py), and so does this implementation when
-        # the lanes of its dot kernels take two adjacent elements instead of one (5.8 % at one trip of one case,
-        # 1e-10 ||r0|| deep); 10 % there
+        # restarted GMRES(10) amplifies rounding noise by ~1e7: the reference itself moves by percents under a
+        # change of its reduction order.  The bound there is the MEASURED envelope: 10x what the oracle (bit-identical
+        # to the reference at one thread) deviates from itself between 1 and 2..6 threads on this very case.
         if s == "-gm" and restart == 10:
-            bound = np.maximum(bound, 1e-1 * w[ok])
+            import sys
+            sys.path.insert(0, HERE)
+            import oracle_py as orc
+            from helpers import oracle_with_noise
+            n, I, J, V = orc.read_mtx(_mtx(m))
+            V, rs = orc.scale_coo(n, I, J, V, sc)
+            rpo, colo, valo = orc.coo_to_crs(n, I, J, V)
+            bo = 1.0 / (rs * rs)
+            nref = oracle_with_noise(orc, rpo, colo, valo, bo, bo, orc.GMRES, precond=orc.PRECOND[pre], restart_len=restart,
+                                     tol=1e-10)
+            env = np.zeros(k); kk = min(k, len(nref["noise"])); env[:kk] = nref["noise"][:kk]
+            if kk and kk < k: env[kk:] = env[kk - 1]
+            bound = np.maximum(bound, 10.0 * env[ok])
         bad = np.nonzero(np.abs(g[ok] - w[ok]) > bound)[0]
         assert bad.size == 0, (key, int(bad[0]), float(g[ok][bad[0]]), float(w[ok][bad[0]]))
 

@@ -1,6 +1,8 @@
 """CPU: pins the oracle (oracle/its_oracle.cpp, CPU restatement of the reference) against
  (a) golden histories captured from the UNMODIFIED compiled reference (tests/golden/make_golden.py),
- (b) the known-answer tables of the reference's own test_suite/test_data.cpp.
+ (b) the solutions (Solver::x_star) the compiled reference ends with, dumped by oracle/ref_xstar_driver.cpp,
+ (c) the known-answer tables of the reference's own test_suite/test_data.cpp,
+ (d) the reference's kernels.hpp called directly (oracle/ref_kernel_probe.cpp; only where /root/reference exists).
 Bit-for-bit at 1 OpenMP thread: the printed %.16g values must parse to the same doubles."""
 import json
 import os
@@ -9,11 +11,13 @@ import numpy as np
 import pytest
 
 import oracle_py as orc
+from helpers import mtx_path
 from iterative_solvers_amd import matgen
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 HIST = json.load(open(os.path.join(G, "reference_histories.json")))
 TABLES = json.load(open(os.path.join(G, "test_data_tables.json")))
+XSTAR = np.load(os.path.join(G, "reference_xstar.npz"), allow_pickle=False)
 KIND = {"-j": orc.JACOBI, "-gs": orc.GAUSS_SEIDEL, "-cg": orc.CG, "-gm": orc.GMRES}
 
 
@@ -27,11 +31,19 @@ def test_history_matches_compiled_reference(key):
     restart = int(mm[1:]); pre = pp[1:]
     exp = HIST[key]
     orc.set_threads(1)
-    n, I, J, V = orc.read_mtx(os.path.join(G, m + ".mtx"))
+    n, I, J, V = orc.read_mtx(mtx_path(m))
     V, rs = orc.scale_coo(n, I, J, V, sc)
     rp, col, val = orc.coo_to_crs(n, I, J, V)
     b = 1.0 / (rs * rs)
     r = orc.solve(rp, col, val, b, b.copy(), KIND[s], precond=orc.PRECOND[pre], restart_len=restart)
+    # the solution the reference holds after save_x_star (dumped through oracle/ref_xstar_driver.cpp): bit for bit
+    if key in XSTAR.files:
+        want_x = XSTAR[key]
+        got_x = r["x_star"]
+        if n > 4096:
+            with np.errstate(all="ignore"):
+                got_x = np.concatenate([got_x[::16], [np.sum(got_x), np.sqrt(np.sum(got_x * got_x))]])
+        assert np.array_equal(got_x, want_x, equal_nan=True), key
     assert r["converged"] == exp["converged"]
     if exp["converged"]:
         assert r["iters"] == exp["iters"]
@@ -80,3 +92,14 @@ def test_zero_diagonal_edge_cases():
         rp, col, val = matgen.crs_from_coo(M["n"], M["I"], M["J"], M["V"])
         D = orc.extract_diag(rp, col, val)
         assert (D == 0).any()
+
+
+def test_kernel_probe_against_reference_headers():
+    """`make -C oracle probe`: every L1 kernel of the reference's kernels.hpp (included from where it lies) against the
+    restatement, bit for bit, on seeded data of 80 lengths.  Needs the reference tree: skipped on the GPU box."""
+    import subprocess
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("/root/reference not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "probe"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "fails=0" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
