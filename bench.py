@@ -49,7 +49,9 @@ def kernel_sources_hash():
     import glob
     import hashlib
     hsh = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "iterative_solvers_amd", "csrc", "*.h*"))):
+    # the files that hold device code (host-side API changes do not invalidate a counter profile)
+    names = ("its_kernels.hip", "its_ell.hip", "its_epilogue.h", "its_device.h", "its_kernels.h")
+    for f in sorted(os.path.join(ROOT, "iterative_solvers_amd", "csrc", nm) for nm in names):
         hsh.update(os.path.basename(f).encode()); hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]
 

@@ -6,7 +6,8 @@ for DESIGN.md; the driver's headline line comes from bench.py):
   C4  power-law irregular matrix, 10 M rows: SpMV scalar-CSR (exact) vs vector-CSR vs SELL-64-sigma,
       Jacobi (correct sweep) and Gauss-Seidel (multicolour sweep)
 
-  python bench_configs.py [c3] [c4] [--small]      (--small: 48^3 / 200k rows, for a quick check)
+  python bench_configs.py [c3] [c4] [--small] [--no-cpu]   (--small: 48^3 / 200k rows, for a quick check;
+                                                            --no-cpu: skip the oracle legs, for profiler passes)
 One JSON line per measurement.  No torch in this process (see iterative_solvers_amd/rendezvous.py).
 """
 from __future__ import annotations
@@ -56,7 +57,12 @@ def spmv_formats(h, n, nnz, tag):
     h.dev_free(xd); h.dev_free(yd)
 
 
+NO_CPU = "--no-cpu" in sys.argv
+
+
 def cpu_trips(rp, col, val, solver, trips, **kw):
+    if NO_CPU:
+        return None, 0
     import oracle_py as orc
     n = len(rp) - 1
     th = min(orc.num_threads(), os.cpu_count() or 1)
