@@ -203,6 +203,18 @@ int its_comm_init_host(its_handle *h, int rank, int world, its_exchange_cb excha
 int its_dist_setup(its_handle *h, int n_nbr, const int *nbr, const int *send_off,
                    const int *send_idx, const int *recv_off);
 
+/* Triangular sweeps (Gauss-Seidel, -p gs) across ranks (methods/gauss_seidel.hpp:144,177,227 on one process): the
+ * natural-order sweep is sequential from rank to rank, so a row-partitioned sweep runs in GLOBAL multicolour order —
+ * the iteration its_solver_setup's ITS_GS_MULTICOLOR documents, identical arithmetic to the reference's sweep on the
+ * colour-permuted global matrix.  The caller orders every rank's owned rows colour by colour (colours from one global
+ * colouring) and passes the cuts: color_ptr[n_colors + 1] over the owned rows, and per neighbour k the colour cuts of
+ * its send list and halo range, send_color_off / recv_color_off[k * (n_colors + 1) + c] (absolute offsets; entry 0 and
+ * entry n_colors of each row equal send_off / recv_off of its_dist_setup).  crs_L then holds, per row, the entries
+ * whose column has an earlier colour (owned or halo), crs_U the rest off the diagonal.  Each colour step ends with an
+ * exchange of that colour's boundary values.  Call after its_dist_setup, before its_solver_setup. */
+int its_dist_set_colors(its_handle *h, int n_colors, const int *color_ptr, const int *send_color_off,
+                        const int *recv_color_off);
+
 #ifdef __cplusplus
 }
 #endif

@@ -459,6 +459,9 @@ static int spmv_dispatch(its_handle *h, const CsrDev &A, const SpmvArgs &a, int 
 int  its_dist_active(const its_handle *h);
 int  its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi);           // halo exchange + SpMV
 int  its_dist_allreduce(its_handle *h, double *dev, int count, int op);  // 0 sum, 1 max (in place)
+int  its_dist_exchange(its_handle *h, double *x, int color);             // boundary values of one colour (or all: -1)
+int  its_dist_n_colors(const its_handle *h);                             // 0: no colour structure given
+const int *its_dist_color_ptr(const its_handle *h);
 
 // y = A x (+ epilogue) for the solver loops: halo exchange first when row-partitioned.
 static int solver_spmv(its_handle *h, const SpmvArgs &a, int epi)
@@ -525,10 +528,17 @@ extern "C" int its_init_residual(its_handle *h, double *r0_inf, double *r0_two)
 // ---------------------------------------------------------------------------------------
 // triangular-sweep schedule: level(i) = 1 + max level(j) over strictly-lower entries of row i
 // ---------------------------------------------------------------------------------------
-static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc)
+// given_ptr != nullptr: the levels are given (the colours of a row-block partition in global multicolour order,
+// rows [given_ptr[c], given_ptr[c+1]) = colour c; columns >= n are halo entries that the exchange after each colour
+// supplies) instead of being derived from the dependencies.
+static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc, const int *given_ptr = nullptr, int n_given = 0)
 {
     std::vector<int> lev(n, 0);
     int nl = 0;
+    if (given_ptr) {
+        nl = n_given;
+        for (int c = 0; c < n_given; ++c) for (int i = given_ptr[c]; i < given_ptr[c + 1]; ++i) lev[i] = c;
+    } else
     for (int i = 0; i < n; ++i) {
         int l = 0;
         for (int k = Lp[i]; k < Lp[i + 1]; ++k) l = std::max(l, lev[Lc[k]] + 1);
@@ -541,7 +551,7 @@ static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc)
     // ordering it degenerates to about one range per row.  Either schedule gives every row the same operands
     // (everything it reads was finished by an earlier launch), so the choice is free: ranges win when they are
     // not many more than the dependency levels, because a range is swept like an SpMV (below).
-    {
+    if (!given_ptr) {
         std::vector<int> rng(n, 0);
         int nr = n ? 1 : 0, start = 0;
         for (int i = 0; i < n; ++i) {
@@ -621,6 +631,7 @@ static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc)
 static int sweep(its_handle *h, double *x, const double *rhs)
 {
     const CsrDev &L = h->mat[ITS_MAT_L];
+    const bool dist = its_dist_active(h);
     for (int l = 0; l < h->n_levels; ++l) {
         const int cnt = h->level_ptr[l + 1] - h->level_ptr[l];
         if (h->level_desc_count[l] > 0 && h->sweep_stream) {
@@ -629,6 +640,9 @@ static int sweep(its_handle *h, double *x, const double *rhs)
         } else {
             launch_sweep_level(L, h->level_rows + h->level_ptr[l], cnt, h->level_nshort[l], x, rhs, h->D, h->stream);
         }
+        // row-partitioned: colour l is done on every rank, its boundary values go to the neighbours before any rank
+        // starts colour l + 1 (stream order on both sides of the exchange)
+        if (dist) { int rc = its_dist_exchange(h, x, l); if (rc) return rc; }
     }
     HIPCHK(h, hipGetLastError());
     return ITS_OK;
@@ -646,16 +660,33 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
     const size_t ne = (size_t)std::max(h->n_ext, n);
     const bool need_L = solver_kind == ITS_GAUSS_SEIDEL || (solver_kind == ITS_GMRES && precond_kind == ITS_PRECOND_GS);
     if (need_L) {
-        if (its_dist_active(h)) FAIL(h, ITS_EUNSUPPORTED, "triangular sweeps are single-GPU in this round");
+        const bool dist = its_dist_active(h);
+        if (dist && its_dist_n_colors(h) == 0)
+            FAIL(h, ITS_EUNSUPPORTED, "row-partitioned triangular sweeps need the global colour structure (its_dist_set_colors): "
+                                      "the natural-order sweep is sequential across ranks");
         if (!h->have[ITS_MAT_L] || (solver_kind == ITS_GAUSS_SEIDEL && !h->have[ITS_MAT_U]))
             FAIL(h, ITS_ESTATE, "upload crs_L / crs_U first (gauss_seidel.hpp:433-450)");
         const CsrDev &L = h->mat[ITS_MAT_L];
+        if (L.n_rows != n) FAIL(h, ITS_EINVAL, "crs_L must have the rows of A");
         std::vector<int> Lp(n + 1), Lc((size_t)L.nnz);
         HIPCHK(h, hipMemcpy(Lp.data(), L.row_ptr, (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost));
         if (L.nnz) HIPCHK(h, hipMemcpy(Lc.data(), L.col, (size_t)L.nnz * sizeof(int), hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; ++i) for (int k = Lp[i]; k < Lp[i + 1]; ++k)
-            if (Lc[k] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
-        int rc = build_levels(h, n, Lp.data(), Lc.data());
+        int rc;
+        if (dist) {
+            // owned columns of a row must belong to earlier colours (strictly lower in the global colour-major order);
+            // halo columns (>= n) are earlier colours of other ranks by the caller's construction
+            const int *cp = its_dist_color_ptr(h);
+            const int nc = its_dist_n_colors(h);
+            for (int c = 0; c < nc; ++c)
+                for (int i = cp[c]; i < cp[c + 1]; ++i)
+                    for (int k = Lp[i]; k < Lp[i + 1]; ++k)
+                        if (Lc[k] < n && Lc[k] >= cp[c]) FAIL(h, ITS_EINVAL, "crs_L: a row reads an owned row of its own or a later colour");
+            rc = build_levels(h, n, Lp.data(), Lc.data(), cp, nc);
+        } else {
+            for (int i = 0; i < n; ++i) for (int k = Lp[i]; k < Lp[i + 1]; ++k)
+                if (Lc[k] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
+            rc = build_levels(h, n, Lp.data(), Lc.data());
+        }
         if (rc) return rc;
     }
     if (solver_kind == ITS_JACOBI && jacobi_mode == ITS_JACOBI_SHIPPED) {
@@ -823,7 +854,7 @@ static int trip_gs(its_handle *h, double *res_out)
     const CsrDev &Am = h->mat[ITS_MAT_A], &Um = h->mat[ITS_MAT_U];
     const bool fused = h->fused_residual && Um.nnz == Am.n_upper && Um.n_upper == Um.nnz &&
                        Um.upper_col_sum == Am.upper_col_sum && Um.upper_val_xor == Am.upper_val_xor &&
-                       Am.max_row_len <= IRR_ROW_LEN;
+                       Am.max_row_len <= IRR_ROW_LEN && !its_dist_active(h);
     if (!(fused && h->ahead)) {
         if ((rc = spmv_dispatch(h, h->mat[ITS_MAT_U], u, EPI_GS_RHS, ITS_FMT_CSR_EXACT))) return rc;   // gauss_seidel.hpp:144,177
     }

@@ -54,6 +54,11 @@ struct DistPlan {
     int *send_idx = nullptr;                 // device
     double *send_buf = nullptr;              // device
     double *host_send = nullptr, *host_recv = nullptr, *host_sc = nullptr;   // pinned (HOST transport)
+    // multicolour sweeps across ranks (its_dist_set_colors): local rows are ordered colour by colour, and so are
+    // every neighbour's send list and halo range; colour c of neighbour k is send_coff[k*(n_colors+1) + c .. + c+1)
+    // of send_idx and recv_coff[...] of the halo
+    int n_colors = 0;
+    std::vector<int> color_ptr, send_coff, recv_coff;
     // row blocks without / with halo columns
     int4 *desc_int = nullptr, *desc_bnd = nullptr;
     int nb_int = 0, nb_bnd = 0;
@@ -260,6 +265,92 @@ extern "C" int its_dist_setup(its_handle *h, int n_nbr, const int *nbr, const in
         return rcs;
     d->plan_ready = true;
     h->setup_done = false; h->residual_done = false;
+    return ITS_OK;
+}
+
+// Colour structure of a partition whose local rows are ordered colour by colour (global multicolour ordering,
+// SURVEY.md §8e "GS across GPUs: colours are global"): color_ptr[n_colors + 1] cuts the owned rows, and for every
+// neighbour k the colour cuts of its send list and of its halo range (absolute offsets into send_idx / the halo,
+// n_nbr x (n_colors + 1) each, row-major).  After this call triangular sweeps run colour by colour with one
+// exchange of the colour's boundary values after each colour.
+extern "C" int its_dist_set_colors(its_handle *h, int n_colors, const int *color_ptr, const int *send_color_off,
+                                   const int *recv_color_off)
+{
+    if (!h || n_colors < 1 || !color_ptr) return ITS_EINVAL;
+    if (!h->dist || !h->dist->plan_ready) FAIL(h, ITS_ESTATE, "its_dist_setup first");
+    DistPlan *d = h->dist;
+    if (d->n_nbr > 0 && (!send_color_off || !recv_color_off)) return ITS_EINVAL;
+    const int n_loc = h->mat[ITS_MAT_A].n_rows;
+    if (color_ptr[0] != 0 || color_ptr[n_colors] != n_loc) FAIL(h, ITS_EINVAL, "color_ptr must cut [0, owned rows)");
+    for (int c = 0; c < n_colors; ++c) if (color_ptr[c + 1] < color_ptr[c]) FAIL(h, ITS_EINVAL, "color_ptr not monotone");
+    const int w = n_colors + 1;
+    for (int k = 0; k < d->n_nbr; ++k) {
+        if (send_color_off[k * w] != d->send_off[k] || send_color_off[k * w + n_colors] != d->send_off[k + 1] ||
+            recv_color_off[k * w] != d->recv_off[k] || recv_color_off[k * w + n_colors] != d->recv_off[k + 1])
+            FAIL(h, ITS_EINVAL, "colour offsets must cut each neighbour's send list / halo range exactly");
+        for (int c = 0; c < n_colors; ++c)
+            if (send_color_off[k * w + c + 1] < send_color_off[k * w + c] || recv_color_off[k * w + c + 1] < recv_color_off[k * w + c])
+                FAIL(h, ITS_EINVAL, "colour offsets not monotone");
+    }
+    d->n_colors = n_colors;
+    d->color_ptr.assign(color_ptr, color_ptr + w);
+    d->send_coff.assign(send_color_off, send_color_off + (size_t)d->n_nbr * w);
+    d->recv_coff.assign(recv_color_off, recv_color_off + (size_t)d->n_nbr * w);
+    h->setup_done = false;
+    return ITS_OK;
+}
+
+int its_dist_n_colors(const its_handle *h) { return h->dist ? h->dist->n_colors : 0; }
+const int *its_dist_color_ptr(const its_handle *h) { return h->dist && h->dist->n_colors ? h->dist->color_ptr.data() : nullptr; }
+
+// Exchange the boundary values of ONE colour of the vector x (owned entries followed by the halo), or of all
+// colours (color < 0), on the compute stream: what a colour step of a triangular sweep publishes to the neighbours.
+int its_dist_exchange(its_handle *h, double *x, int color)
+{
+    DistPlan *d = h->dist;
+    if (!d || !d->plan_ready) FAIL(h, ITS_ESTATE, "no exchange plan");
+    if (color >= d->n_colors) FAIL(h, ITS_EINVAL, "colour out of range");
+    const int n_loc = h->mat[ITS_MAT_A].n_rows;
+    const int w = d->n_colors + 1;
+    std::vector<int> s0(d->n_nbr), s1(d->n_nbr), r0(d->n_nbr), r1(d->n_nbr);
+    int tot_s = 0, tot_r = 0;
+    for (int k = 0; k < d->n_nbr; ++k) {
+        if (color < 0) { s0[k] = d->send_off[k]; s1[k] = d->send_off[k + 1]; r0[k] = d->recv_off[k]; r1[k] = d->recv_off[k + 1]; }
+        else { s0[k] = d->send_coff[k * w + color]; s1[k] = d->send_coff[k * w + color + 1]; r0[k] = d->recv_coff[k * w + color]; r1[k] = d->recv_coff[k * w + color + 1]; }
+        tot_s += s1[k] - s0[k]; tot_r += r1[k] - r0[k];
+    }
+    for (int k = 0; k < d->n_nbr; ++k) {
+        const int cnt = s1[k] - s0[k];
+        if (cnt > 0)
+            hipLaunchKernelGGL(pack_kernel, dim3((cnt + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, h->stream,
+                               x, d->send_idx + s0[k], d->send_buf + s0[k], cnt);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (d->transport == 1) {
+        if (tot_s + tot_r == 0) return ITS_OK;
+        NCCLCHK(h, ncclGroupStart());
+        for (int k = 0; k < d->n_nbr; ++k) {
+            if (s1[k] > s0[k]) NCCLCHK(h, ncclSend(d->send_buf + s0[k], s1[k] - s0[k], ncclDouble, d->nbr[k], d->comm_halo, h->stream));
+            if (r1[k] > r0[k]) NCCLCHK(h, ncclRecv(x + n_loc + r0[k], r1[k] - r0[k], ncclDouble, d->nbr[k], d->comm_halo, h->stream));
+        }
+        NCCLCHK(h, ncclGroupEnd());
+        return ITS_OK;
+    }
+    // HOST transport: compact the segments, hand them to the callback (every rank calls it, also with nothing to
+    // send: the callback is a collective), scatter what came back
+    std::vector<int> so(d->n_nbr + 1, 0), ro(d->n_nbr + 1, 0);
+    for (int k = 0; k < d->n_nbr; ++k) {
+        so[k + 1] = so[k] + (s1[k] - s0[k]); ro[k + 1] = ro[k] + (r1[k] - r0[k]);
+        if (s1[k] > s0[k])
+            HIPCHK(h, hipMemcpyAsync(d->host_send + so[k], d->send_buf + s0[k], (size_t)(s1[k] - s0[k]) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (d->xcb(d->user, d->host_send, so.data(), d->host_recv, ro.data(), d->nbr.data(), d->n_nbr) != 0)
+        FAIL(h, ITS_ECOMM, "host exchange callback failed");
+    for (int k = 0; k < d->n_nbr; ++k)
+        if (r1[k] > r0[k])
+            HIPCHK(h, hipMemcpyAsync(x + n_loc + r0[k], d->host_recv + ro[k], (size_t)(r1[k] - r0[k]) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));       // host_recv is reused by the next exchange
     return ITS_OK;
 }
 

@@ -40,20 +40,34 @@ def main():
     n_loc = len(rp) - 1
     h = capi.Handle(0)
     D.init_comm_host(h, rank, world, rdzv)
-    plan = D.upload_slab(h, rdzv, n_global, row_begin, rp, colg, val, capi.FMT_CSR_EXACT)
+    owned = None
+    if solver in ("gs", "gmres_pgs"):
+        # triangular sweeps across ranks: global multicolour order (distributed.plan_colored); every rank builds the
+        # global matrix here (test sizes) and owns the rows of its contiguous block of ORIGINAL rows
+        rpg, cg, vg = matgen.laplace3d_7pt(12, nz=24) if kind == "lap" else matgen.powerlaw(6000)
+        cp = D.plan_colored(rdzv, rpg, cg, vg, row_begin, row_begin + n_loc)
+        D.upload_colored(h, cp)
+        plan = cp.base
+        diag = cp.diag
+        owned = cp.owned_global
+    else:
+        plan = D.upload_slab(h, rdzv, n_global, row_begin, rp, colg, val, capi.FMT_CSR_EXACT)
     h.upload_vectors(diag, np.ones(n_loc), np.ones(n_loc))
     r0_inf, r0_two = h.init_residual()
-    kindmap = {"cg": capi.CG, "jacobi": capi.JACOBI, "gmres": capi.GMRES}
-    h.solver_setup(kindmap[solver], restart_len=10, jacobi_mode=capi.JACOBI_REF)
+    kindmap = {"cg": capi.CG, "jacobi": capi.JACOBI, "gmres": capi.GMRES, "gs": capi.GAUSS_SEIDEL, "gmres_pgs": capi.GMRES}
+    h.solver_setup(kindmap[solver], restart_len=10, jacobi_mode=capi.JACOBI_REF,
+                   precond=capi.PRECOND_GS if solver == "gmres_pgs" else capi.PRECOND_NONE,
+                   gs_order=capi.GS_MULTICOLOR if owned is not None else capi.GS_LEVEL)
     trips = 30
     hist = []
     for it in range(trips):
         hist.append(h.iterate(it))
-        if solver == "gmres" and (it + 1) % 10 == 0 and it + 1 < trips:
+        if solver in ("gmres", "gmres_pgs") and (it + 1) % 10 == 0 and it + 1 < trips:
             h.gmres_restart(it)
     x = h.download_x(n_loc, trips)
     json.dump({"rank": rank, "row_begin": row_begin, "n_loc": n_loc, "n_halo": plan.n_halo, "nbr": plan.nbr.tolist(),
-               "r0_inf": r0_inf, "r0_two": r0_two, "hist": hist, "x": x.tolist()}, open(f"{out}.{rank}.json", "w"))
+               "r0_inf": r0_inf, "r0_two": r0_two, "hist": hist, "x": x.tolist(),
+               "owned": owned.tolist() if owned is not None else None}, open(f"{out}.{rank}.json", "w"))
     rdzv.barrier()
     h.close(); rdzv.close()
 

@@ -100,6 +100,78 @@ def test_partition_plan_gloo(world, kind):
     assert all(s == "ok" for _, s in res), res
 
 
+def _colored_worker(rank, world, port, kind, q):
+    """Gauss-Seidel across ranks in global multicolour order (distributed.plan_colored): every colour is swept by all
+    ranks, then its boundary values are exchanged.  Must reproduce the reference's natural-order sweep on the
+    colour-permuted global matrix (what the oracle runs) — the arithmetic per row is the same."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import oracle_py as orc
+    from iterative_solvers_amd import capi, distributed as D, matgen
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc.set_threads(1)
+
+    class Gloo:
+        def __init__(self):
+            self.rank, self.world = rank, world
+
+        def allgather_bytes(self, b):
+            out = [None] * world
+            dist.all_gather_object(out, b)
+            return out
+
+    comm = Gloo()
+    try:
+        rpg, cg, vg = matgen.laplace3d_7pt(6, nz=12) if kind == "lap" else matgen.powerlaw(900)
+        n = len(rpg) - 1
+        cuts = np.linspace(0, n, world + 1).astype(int)
+        cp = D.plan_colored(comm, rpg, cg, vg, int(cuts[rank]), int(cuts[rank + 1]))
+        b_ = cp.base
+        n_loc = b_.n_loc
+        # every rank's rows, L, U and diagonal are those of B = Q A Q^T
+        perm, nc = capi.multicolor_order(rpg, cg)
+        rpB, colB, valB = capi.permute_crs(rpg, cg, vg, perm)
+        assert cp.n_colors == nc and cp.color_ptr[-1] == n_loc
+        ref = orc.solve(rpB, colB, valB, np.ones(n), np.ones(n), orc.GAUSS_SEIDEL, fixed_iters=6, max_iters=6)
+        Lp, Lc, Lv = cp.L; Up, Uc, Uv = cp.U
+        x = np.zeros(n_loc + b_.n_halo)                                  # the reference's GS starts from Solver::x = 0
+        rhs_b = np.ones(n_loc)
+        for _ in range(6):
+            tmp = rhs_b - orc.spmv(Up, Uc, Uv, x)                        # gauss_seidel.hpp:144,177 (halo of x is current)
+            for c in range(cp.n_colors):
+                for i in range(cp.color_ptr[c], cp.color_ptr[c + 1]):   # kernels.hpp:460-472, rows of one colour
+                    s_ = 0.0
+                    for k in range(Lp[i], Lp[i + 1]):
+                        s_ += Lv[k] * x[Lc[k]]
+                    x[i] = (tmp[i] - s_) / cp.diag[i]
+                D.exchange_color_host(comm, cp, x, c)
+        want = ref["x_star"][cp.owned_global]
+        assert np.allclose(x[:n_loc], want, rtol=1e-12, atol=1e-13), float(np.max(np.abs(x[:n_loc] - want)))
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "lap"), (3, "lap"), (3, "pl")])
+def test_colored_gauss_seidel_partition_gloo(world, kind):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world * 11 + (5 if kind == "pl" else 0)
+    procs = [ctx.Process(target=_colored_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(s == "ok" for _, s in res), res
+
+
 def _rdzv_worker(rank, world, key, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=key, RANK=str(rank), WORLD_SIZE=str(world))

@@ -59,6 +59,49 @@ def test_host_transport_multi_process(tmp_path, world, kind, solver):
         assert res[1]["n_halo"] == 2 * 144
 
 
+@pytest.mark.parametrize("world,kind,solver", [(2, "lap", "gs"), (3, "lap", "gs"), (3, "pl", "gs"), (2, "lap", "gmres_pgs"),
+                                                (3, "pl", "gmres_pgs")])
+def test_host_transport_triangular_sweeps_across_ranks(tmp_path, world, kind, solver):
+    """Gauss-Seidel and GS-preconditioned GMRES row-partitioned over 2 / 3 processes (HOST transport, one GPU): the
+    sweep runs in GLOBAL multicolour order, one exchange of a colour's boundary values after each colour
+    (its_dist_set_colors).  Reference: the oracle's natural-order sweep on the same colour-permuted global matrix
+    B = Q A Q^T — identical arithmetic per row, so Gauss-Seidel iterates must agree to rounding of nothing at all
+    (bit-exact x), GMRES within the usual reduction-order tolerance."""
+    out = str(tmp_path / "res")
+    port = 33000 + os.getpid() % 3000 + world
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ITS_RDZV_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), kind, solver, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=110)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    res = [json.load(open(f"{out}.{r}.json")) for r in range(world)]
+    rp, col, val = _global_problem(kind)
+    n = len(rp) - 1
+    perm, nc = capi.multicolor_order(rp, col)
+    rpB, colB, valB = capi.permute_crs(rp, col, val, perm)
+    orc.set_threads(1)
+    if solver == "gs":
+        ref = orc.solve(rpB, colB, valB, np.ones(n), np.ones(n), orc.GAUSS_SEIDEL, fixed_iters=30, max_iters=30)
+    else:
+        ref = orc.solve(rpB, colB, valB, np.ones(n), np.ones(n), orc.GMRES, precond=orc.PRECOND["gs"], restart_len=10,
+                        fixed_iters=30, max_iters=30)
+    xB = np.empty(n)
+    for r in res:
+        xB[np.array(r["owned"], dtype=np.int64)] = np.array(r["x"])
+        assert r["hist"] == res[0]["hist"]
+    exp = ref["all_values"]
+    k = min(len(exp), 30)
+    got = np.array(res[0]["hist"][:k])
+    assert np.all(np.abs(got - exp[:k]) <= 1e-10 * np.maximum(exp[:k], 1e-2 * ref["r0_two"]))
+    if solver == "gs":
+        assert np.array_equal(xB, ref["x_star"])          # no reduction touches a Gauss-Seidel iterate
+    else:
+        assert np.max(np.abs(xB - ref["x_star"])) <= 1e-10 * max(1.0, np.max(np.abs(ref["x_star"])))
+
+
 def test_rccl_world_one_matches_single_gpu():
     import ctypes as C
     rp, col, val = matgen.laplace3d_7pt(16)
