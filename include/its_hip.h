@@ -167,6 +167,12 @@ int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, doub
  * the order below (rows colour by colour) and uploads P A P^T, P b, P x0: the levels of the
  * permuted strict-lower part are then the colours, and a CPU reference run on the same permuted
  * matrix performs the identical arithmetic. */
+/* extract_diag (utility_funcs.hpp:157-174) and split_L_U + convert_to_crs (utility_funcs.hpp:240-324,
+ * methods/gauss_seidel.hpp:433-450) on the host, OpenMP-parallel: what a caller that holds A in CRS needs before
+ * its_upload_vectors / the ITS_MAT_L, ITS_MAT_U uploads.  L / U outputs sized like the inputs. */
+int its_extract_diag(int n, const int *row_ptr, const int *col, const double *val, double *D);
+int its_split_lu(int n, const int *row_ptr, const int *col, const double *val,
+                 int *Lp, int *Lc, double *Lv, int *Up, int *Uc, double *Uv);
 /* greedy distance-1 colouring of the graph of A + A^T in natural vertex order;
  * perm_new2old[n]: rows listed colour by colour, ascending inside a colour */
 int its_multicolor_order(int n, const int *row_ptr, const int *col, int *perm_new2old, int *n_colors);

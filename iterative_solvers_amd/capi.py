@@ -60,6 +60,8 @@ SIGNATURES = {
     "its_last_spmv_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "its_spmv_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, _c_i64_p]),
     "its_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_int_p, _c_dbl_p, _c_int_p]),
+    "its_extract_diag": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "its_split_lu": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
     "its_multicolor_order": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _c_int_p]),
     "its_permute_crs": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "its_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -102,6 +104,32 @@ def multicolor_order(row_ptr, col):
     if rc != 0:
         raise ItsError(f"its_multicolor_order failed ({rc})")
     return perm, nc.value
+
+
+def extract_diag(row_ptr, col, val):
+    """Host-only, OpenMP: extract_diag (utility_funcs.hpp:157-174)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32); col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    n = len(row_ptr) - 1
+    D = np.empty(n)
+    rc = lib().its_extract_diag(n, row_ptr.ctypes.data, col.ctypes.data, val.ctypes.data, D.ctypes.data)
+    if rc != 0:
+        raise ItsError(f"its_extract_diag failed ({rc})")
+    return D
+
+
+def split_lu(row_ptr, col, val):
+    """Host-only, OpenMP: strictly lower / strictly upper part in CRS (split_L_U, utility_funcs.hpp:240-324)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32); col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    n = len(row_ptr) - 1; nnz = len(col)
+    Lp = np.empty(n + 1, np.int32); Up = np.empty(n + 1, np.int32)
+    Lc = np.empty(nnz, np.int32); Uc = np.empty(nnz, np.int32); Lv = np.empty(nnz); Uv = np.empty(nnz)
+    rc = lib().its_split_lu(n, row_ptr.ctypes.data, col.ctypes.data, val.ctypes.data, Lp.ctypes.data, Lc.ctypes.data,
+                            Lv.ctypes.data, Up.ctypes.data, Uc.ctypes.data, Uv.ctypes.data)
+    if rc != 0:
+        raise ItsError(f"its_split_lu failed ({rc})")
+    return (Lp, Lc[:Lp[-1]], Lv[:Lp[-1]]), (Up, Uc[:Up[-1]], Uv[:Up[-1]])
 
 
 def permute_crs(row_ptr, col, val, perm_new2old):

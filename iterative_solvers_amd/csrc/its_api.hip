@@ -2,6 +2,7 @@
 // Host-side state machine that mirrors Solver<VT> (reference solver.hpp) with every vector
 // resident in HBM; the only per-trip host traffic is one 8-byte scalar (GMRES: one H column).
 #include "its_handle.h"
+#include "its_hostplan.h"
 
 #include <algorithm>
 #include <atomic>
@@ -19,6 +20,20 @@
 // overrides the environment (tests exercise all three against each other).
 static int g_readback_mode = getenv("ITS_READBACK_COPY") ? 2 : getenv("ITS_READBACK_SYNC") ? 1 : 0;
 static inline int readback_mode() { return g_readback_mode; }
+
+// ITS_TIMING=1: wall time of the set-up phases on stderr (uploads, plans, schedules): what SURVEY.md §8f.2 asks to
+// be kept off the serial host path
+struct PhaseTimer {
+    bool on; std::chrono::steady_clock::time_point t0; const char *ctx;
+    explicit PhaseTimer(const char *c) : on(getenv("ITS_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), ctx(c) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[its timing] %s / %s: %.1f ms\n", ctx, what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 static void free_csr(CsrDev &A)
 {
@@ -229,10 +244,15 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) FAIL(h, ITS_EINVAL, "row_ptr[0] != 0 or row_ptr[n] != nnz");
     if (nnz > INT32_MAX - 16) FAIL(h, ITS_EUNSUPPORTED, "nnz exceeds int32 offsets (sparse_matrix.hpp:20-27)");
     HIPCHK(h, hipSetDevice(h->device));
+    PhaseTimer pt(which == ITS_MAT_A ? "upload A" : which == ITS_MAT_L ? "upload L" : "upload U");
     // validate what the kernels assume BEFORE anything of the old matrix is given up: monotone row_ptr, columns
     // inside [0, n_cols).  A rejected upload leaves the handle as it was.
-    for (int i = 0; i < n_rows; ++i) if (row_ptr[i + 1] < row_ptr[i]) FAIL(h, ITS_EINVAL, "row_ptr not monotone");
-    for (int64_t k = 0; k < nnz; ++k) if (col[k] < 0 || col[k] >= n_cols) FAIL(h, ITS_EINVAL, "column index out of range");
+    {
+        const int bad = its_host::validate_crs(n_rows, n_cols, nnz, row_ptr, col);
+        if (bad == 1) FAIL(h, ITS_EINVAL, "row_ptr not monotone");
+        if (bad == 2) FAIL(h, ITS_EINVAL, "column index out of range");
+    }
+    pt.lap("validate");
     CsrDev &A = h->mat[which];
     // from here on the old matrix is gone: whatever was derived from it goes with it, and a failure below leaves
     // the slot empty (have[which] false), never half-built
@@ -242,6 +262,7 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     if (which == ITS_MAT_L) {                     // the sweep schedule describes the old L
         dfree(h->level_rows); dfree(h->sweep_desc);
         h->n_levels = 0; h->level_ptr.clear(); h->level_nshort.clear(); h->level_desc_first.clear(); h->level_desc_count.clear();
+        h->L_rp.clear(); h->L_maxcol.clear();
     }
     free_csr(A);
     A.n_rows = n_rows; A.n_cols = n_cols; A.nnz = nnz;
@@ -254,96 +275,60 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         HIPCHK(h, hipMemcpy(A.col, col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(A.val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
     }
+    pt.lap("copy CRS to the device");
     {
-        // column-offset dictionary: at most 256 distinct (col - row) over the whole matrix
-        const int64_t span = (int64_t)n_rows + n_cols + 1;
-        std::vector<int16_t> slot((size_t)span, (int16_t)-1);
-        std::vector<int> dict;
+        // column-offset dictionary: at most 256 distinct (col - row) over the whole matrix; value dictionary: at most
+        // 256 distinct fp64 bit patterns (constant-coefficient stencils).  Both in first-occurrence order, built by the
+        // OpenMP passes of its_host.cpp.
         std::vector<unsigned char> cidx((size_t)nnz + CSR_PAD, 0);
-        bool ok = nnz > 0 && getenv("ITS_NO_OFFSET_DICT") == nullptr;
-        for (int i = 0; i < n_rows && ok; ++i)
-            for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
-                int16_t &sl = slot[(size_t)(col[k] - i + n_rows)];
-                if (sl < 0) {
-                    if (dict.size() == 256) { ok = false; break; }
-                    sl = (int16_t)dict.size();
-                    dict.push_back(col[k] - i);
-                }
-                cidx[k] = (unsigned char)sl;
-            }
+        int dict[256]; int n_off = 0;
+        const bool ok = nnz > 0 && getenv("ITS_NO_OFFSET_DICT") == nullptr &&
+                        its_host::offset_dict(n_rows, row_ptr, col, cidx.data(), dict, &n_off);
         if (ok) {
-            A.n_off = (int)dict.size();
-            dict.resize(256, 0);
+            A.n_off = n_off;
             if (dalloc(h, &A.cidx, cidx.size()) || dalloc(h, &A.off_dict, 256)) return ITS_EHIP;
             HIPCHK(h, hipMemcpy(A.cidx, cidx.data(), cidx.size(), hipMemcpyHostToDevice));
-            HIPCHK(h, hipMemcpy(A.off_dict, dict.data(), 256 * sizeof(int), hipMemcpyHostToDevice));
-        }
-        // value dictionary: at most 256 distinct fp64 bit patterns (constant-coefficient stencils)
-        if (ok) {
-            std::vector<uint64_t> keys(1024, 0); std::vector<int16_t> ids(1024, (int16_t)-1);
-            std::vector<double> vd;
+            HIPCHK(h, hipMemcpy(A.off_dict, dict, 256 * sizeof(int), hipMemcpyHostToDevice));
+            double vd[256]; int n_vals = 0;
             std::vector<unsigned char> &vidx = cidx;                   // reuse the host buffer
-            bool vok = true;
-            for (int64_t k = 0; k < nnz && vok; ++k) {
-                uint64_t bits; memcpy(&bits, &val[k], 8);
-                size_t p = (size_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);
-                while (ids[p] >= 0 && keys[p] != bits) p = (p + 1) & 1023;
-                if (ids[p] < 0) {
-                    if (vd.size() == 256) { vok = false; break; }
-                    ids[p] = (int16_t)vd.size(); keys[p] = bits; vd.push_back(val[k]);
-                }
-                vidx[k] = (unsigned char)ids[p];
-            }
-            if (vok) {
-                A.n_vals = (int)vd.size();
-                vd.resize(256, 0.0);
+            if (its_host::value_dict(nnz, val, vidx.data(), vd, &n_vals)) {
+                A.n_vals = n_vals;
                 if (dalloc(h, &A.vidx, vidx.size()) || dalloc(h, &A.val_dict, 256)) return ITS_EHIP;
                 HIPCHK(h, hipMemcpy(A.vidx, vidx.data(), vidx.size(), hipMemcpyHostToDevice));
-                HIPCHK(h, hipMemcpy(A.val_dict, vd.data(), 256 * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK(h, hipMemcpy(A.val_dict, vd, 256 * sizeof(double), hipMemcpyHostToDevice));
             }
         }
     }
-    std::vector<int> blk;
+    pt.lap("offset / value dictionaries");
+    std::vector<int> blk, longest;
     build_stream_plan(n_rows, row_ptr, blk);
     A.n_blocks = (int)blk.size() - 1;
     std::vector<int4> desc(std::max(A.n_blocks, 1));
-    for (int i = 0; i < A.n_blocks; ++i) {
-        // .y = rows | (longest row of the block, capped) << 16: the kernel's batch count
-        int longest = 0;
-        for (int r = blk[i]; r < blk[i + 1]; ++r) longest = std::max(longest, row_ptr[r + 1] - row_ptr[r]);
-        desc[i] = make_int4(blk[i], (blk[i + 1] - blk[i]) | (std::min(longest, 0x7fff) << 16), row_ptr[blk[i]], row_ptr[blk[i + 1]]);
-    }
+    longest.assign(std::max(A.n_blocks, 1), 0);
+    its_host::block_longest(A.n_blocks, blk.data(), row_ptr, longest.data());
+    // .y = rows | (longest row of the block, capped) << 16: the kernel's batch count
+    for (int i = 0; i < A.n_blocks; ++i)
+        desc[i] = make_int4(blk[i], (blk[i + 1] - blk[i]) | (std::min(longest[i], 0x7fff) << 16), row_ptr[blk[i]], row_ptr[blk[i + 1]]);
     if (dalloc(h, &A.blk_desc, desc.size())) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.blk_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
-    int longest_row = 0;
-    for (int i = 0; i < n_rows; ++i) longest_row = std::max(longest_row, row_ptr[i + 1] - row_ptr[i]);
-    if (longest_row <= 8 && n_rows > 0) {
+    // longest row; and what trip_gs compares between A and crs_U before it lets one pass over A stand in for the pass
+    // over U: count, column sum and an order-independent hash of the value bits of the entries right of the diagonal
+    its_host::row_stats(n_rows, row_ptr, col, val, which != ITS_MAT_L, &A.max_row_len, &A.n_upper, &A.upper_col_sum, &A.upper_val_xor);
+    if (A.max_row_len <= 8 && n_rows > 0) {
         // rows this short may run on spmv_stream4_kernel, which takes larger row blocks (its_kernels.h)
         build_stream_plan(n_rows, row_ptr, blk, ITS_BLOCK, SPMV_NNZ_BIG);
         A.n_blocks_big = (int)blk.size() - 1;
         desc.assign(std::max(A.n_blocks_big, 1), make_int4(0, 0, 0, 0));
-        for (int i = 0; i < A.n_blocks_big; ++i) {
-            int longest = 0;
-            for (int r = blk[i]; r < blk[i + 1]; ++r) longest = std::max(longest, row_ptr[r + 1] - row_ptr[r]);
-            desc[i] = make_int4(blk[i], (blk[i + 1] - blk[i]) | (longest << 16), row_ptr[blk[i]], row_ptr[blk[i + 1]]);
-        }
+        longest.assign(std::max(A.n_blocks_big, 1), 0);
+        its_host::block_longest(A.n_blocks_big, blk.data(), row_ptr, longest.data());
+        for (int i = 0; i < A.n_blocks_big; ++i)
+            desc[i] = make_int4(blk[i], (blk[i + 1] - blk[i]) | (longest[i] << 16), row_ptr[blk[i]], row_ptr[blk[i + 1]]);
         if (dalloc(h, &A.blk_desc_big, desc.size())) return ITS_EHIP;
         HIPCHK(h, hipMemcpy(A.blk_desc_big, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
     }
-    A.max_row_len = 0;
-    for (int i = 0; i < n_rows; ++i) A.max_row_len = std::max(A.max_row_len, row_ptr[i + 1] - row_ptr[i]);
     A.lanes_per_row = pick_lanes_per_row(n_rows, nnz, A.max_row_len);
-    // what trip_gs compares between A and crs_U before it lets one pass over A stand in for the pass over U:
-    // count, column sum and an order-independent hash of the value bits of the entries right of the diagonal
-    A.n_upper = 0; A.upper_col_sum = 0; A.upper_val_xor = 0;
-    if (which != ITS_MAT_L)
-        for (int i = 0; i < n_rows; ++i)
-            for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
-                if (col[k] > i) {
-                    uint64_t bits; memcpy(&bits, &val[k], 8);
-                    ++A.n_upper; A.upper_col_sum += col[k]; A.upper_val_xor ^= bits * 0x9E3779B97F4A7C15ull + (uint64_t)col[k];
-                }
-    if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; }
+    pt.lap("stream plans + statistics");
+    if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; pt.lap("SELL image"); }
     // sliced ELL image for short regular rows (its_ell.hip), built on the device from the arrays just uploaded
     if (A.n_off >= 1 && A.n_off <= ELL_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELL_MAX_W && n_rows > 0 &&
         getenv("ITS_NO_ELL") == nullptr) {
@@ -363,6 +348,13 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
+    }
+    pt.lap("ELL image");
+    if (which == ITS_MAT_L) {
+        h->L_rp.assign(row_ptr, row_ptr + n_rows + 1);
+        h->L_maxcol.assign((size_t)std::max(n_rows, 1), -1);
+        its_host::row_maxcol(n_rows, row_ptr, col, n_rows, h->L_maxcol.data());
+        pt.lap("row structure of L for the sweep schedule");
     }
     h->have[which] = true;
     if (which == ITS_MAT_A) { h->fmt = format; h->setup_done = false; h->residual_done = false; }
@@ -528,40 +520,49 @@ extern "C" int its_init_residual(its_handle *h, double *r0_inf, double *r0_two)
 // ---------------------------------------------------------------------------------------
 // triangular-sweep schedule: level(i) = 1 + max level(j) over strictly-lower entries of row i
 // ---------------------------------------------------------------------------------------
+// Sweep schedule of the uploaded crs_L from its host-side row structure (its_handle::L_rp, L_maxcol).
 // given_ptr != nullptr: the levels are given (the colours of a row-block partition in global multicolour order,
 // rows [given_ptr[c], given_ptr[c+1]) = colour c; columns >= n are halo entries that the exchange after each colour
 // supplies) instead of being derived from the dependencies.
-static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc, const int *given_ptr = nullptr, int n_given = 0)
+static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, int n_given = 0)
 {
+    const int *Lp = h->L_rp.data();
+    const int *maxcol = h->L_maxcol.data();
     std::vector<int> lev(n, 0);
     int nl = 0;
     if (given_ptr) {
         nl = n_given;
         for (int c = 0; c < n_given; ++c) for (int i = given_ptr[c]; i < given_ptr[c + 1]; ++i) lev[i] = c;
-    } else
-    for (int i = 0; i < n; ++i) {
-        int l = 0;
-        for (int k = Lp[i]; k < Lp[i + 1]; ++k) l = std::max(l, lev[Lc[k]] + 1);
-        lev[i] = l; nl = std::max(nl, l + 1);
-    }
-    if (n == 0) nl = 0;
-    // Alternative schedule: cut the rows, in order, into contiguous ranges without internal dependencies (a new
-    // range starts at the first row that reads a row of the current one).  For a colour-by-colour ordering this
-    // recovers the colours (dependency levels would scatter a colour's rows over earlier levels); for a natural
-    // ordering it degenerates to about one range per row.  Either schedule gives every row the same operands
-    // (everything it reads was finished by an earlier launch), so the choice is free: ranges win when they are
-    // not many more than the dependency levels, because a range is swept like an SpMV (below).
-    if (!given_ptr) {
+    } else {
+        // Schedule 1: cut the rows, in order, into contiguous ranges without internal dependencies (a new range
+        // starts at the first row that reads a row of the current one).  For a colour-by-colour ordering this
+        // recovers the colours (dependency levels would scatter a colour's rows over earlier levels); for a natural
+        // ordering it degenerates to about one range per row.  Needs only the largest column of every row.
         std::vector<int> rng(n, 0);
         int nr = n ? 1 : 0, start = 0;
         for (int i = 0; i < n; ++i) {
-            bool dep = false;
-            for (int k = Lp[i]; k < Lp[i + 1] && !dep; ++k) dep = Lc[k] >= start;
-            if (dep) { start = i; ++nr; }
+            if (maxcol[i] >= start) { start = i; ++nr; }
             rng[i] = nr - 1;
         }
-        if (nr <= 2 * nl + 16) { lev.swap(rng); nl = nr; }
+        if (n == 0) nr = 0;
+        if (nr <= 64) { lev.swap(rng); nl = nr; }            // a colour ordering: no need to look at the columns at all
+        else {
+            // Schedule 2: dependency levels, level(i) = 1 + max level(j) over the entries of row i (needs the columns:
+            // copied back from the device, this is the natural-order case).  Either schedule gives every row the same
+            // operands (everything it reads was finished by an earlier launch), so the choice is free: ranges win when
+            // they are not many more than the levels, because a range is swept like an SpMV (below).
+            const CsrDev &L = h->mat[ITS_MAT_L];
+            std::vector<int> Lc((size_t)L.nnz);
+            if (L.nnz) HIPCHK(h, hipMemcpy(Lc.data(), L.col, (size_t)L.nnz * sizeof(int), hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i) {
+                int l = 0;
+                for (int k = Lp[i]; k < Lp[i + 1]; ++k) l = std::max(l, lev[Lc[k]] + 1);
+                lev[i] = l; nl = std::max(nl, l + 1);
+            }
+            if (nr <= 2 * nl + 16) { lev.swap(rng); nl = nr; }
+        }
     }
+    if (n == 0) nl = 0;
     h->n_levels = nl;
     h->level_ptr.assign(nl + 1, 0);
     for (int i = 0; i < n; ++i) ++h->level_ptr[lev[i] + 1];
@@ -591,10 +592,11 @@ static int build_levels(its_handle *h, int n, const int *Lp, const int *Lc, cons
         h->level_desc_first[l] = (int)desc.size();
         const int nbl = h->level_desc_count[l] = (int)blk.size() - 1;
         std::vector<int4> hubs, rest;
+        std::vector<int> longest_of(blk.size(), 0);
+        its_host::block_longest(nbl, blk.data(), Lp + lo, longest_of.data());
         for (size_t i = 0; i + 1 < blk.size(); ++i) {
             const int r0 = lo + blk[i], r1 = lo + blk[i + 1];
-            int longest = 0;
-            for (int r = r0; r < r1; ++r) longest = std::max(longest, Lp[r + 1] - Lp[r]);
+            const int longest = longest_of[i];
             const int4 d4 = make_int4(r0, (r1 - r0) | (std::min(longest, 0x7fff) << 16), Lp[r0], Lp[r1]);
             (longest >= SWEEP_HUB ? hubs : rest).push_back(d4);
         }
@@ -659,6 +661,7 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
     const int n = h->n;
     const size_t ne = (size_t)std::max(h->n_ext, n);
     const bool need_L = solver_kind == ITS_GAUSS_SEIDEL || (solver_kind == ITS_GMRES && precond_kind == ITS_PRECOND_GS);
+    PhaseTimer pt("solver_setup");
     if (need_L) {
         const bool dist = its_dist_active(h);
         if (dist && its_dist_n_colors(h) == 0)
@@ -667,10 +670,7 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         if (!h->have[ITS_MAT_L] || (solver_kind == ITS_GAUSS_SEIDEL && !h->have[ITS_MAT_U]))
             FAIL(h, ITS_ESTATE, "upload crs_L / crs_U first (gauss_seidel.hpp:433-450)");
         const CsrDev &L = h->mat[ITS_MAT_L];
-        if (L.n_rows != n) FAIL(h, ITS_EINVAL, "crs_L must have the rows of A");
-        std::vector<int> Lp(n + 1), Lc((size_t)L.nnz);
-        HIPCHK(h, hipMemcpy(Lp.data(), L.row_ptr, (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost));
-        if (L.nnz) HIPCHK(h, hipMemcpy(Lc.data(), L.col, (size_t)L.nnz * sizeof(int), hipMemcpyDeviceToHost));
+        if (L.n_rows != n || (int)h->L_rp.size() != n + 1) FAIL(h, ITS_EINVAL, "crs_L must have the rows of A");
         int rc;
         if (dist) {
             // owned columns of a row must belong to earlier colours (strictly lower in the global colour-major order);
@@ -679,16 +679,16 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
             const int nc = its_dist_n_colors(h);
             for (int c = 0; c < nc; ++c)
                 for (int i = cp[c]; i < cp[c + 1]; ++i)
-                    for (int k = Lp[i]; k < Lp[i + 1]; ++k)
-                        if (Lc[k] < n && Lc[k] >= cp[c]) FAIL(h, ITS_EINVAL, "crs_L: a row reads an owned row of its own or a later colour");
-            rc = build_levels(h, n, Lp.data(), Lc.data(), cp, nc);
+                    if (h->L_maxcol[i] >= cp[c]) FAIL(h, ITS_EINVAL, "crs_L: a row reads an owned row of its own or a later colour");
+            rc = build_levels(h, n, cp, nc);
         } else {
-            for (int i = 0; i < n; ++i) for (int k = Lp[i]; k < Lp[i + 1]; ++k)
-                if (Lc[k] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
-            rc = build_levels(h, n, Lp.data(), Lc.data());
+            for (int i = 0; i < n; ++i)
+                if (h->L_maxcol[i] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
+            rc = build_levels(h, n);
         }
         if (rc) return rc;
     }
+    pt.lap("sweep schedule");
     if (solver_kind == ITS_JACOBI && jacobi_mode == ITS_JACOBI_SHIPPED) {
         // The shipped sweep gathers from x_new, which is still all zeros on the first trip
         // (solver.hpp:225); x_old = x0 is overwritten by the swapped SpMV (jacobi.hpp:191)
@@ -1318,14 +1318,10 @@ extern "C" int its_spltsv(its_handle *h, double *x_dev, const double *rhs_dev)
     if (!h->have[ITS_MAT_L] || !h->D) FAIL(h, ITS_ESTATE, "needs crs_L and D");
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->level_rows) {
-        const CsrDev &L = h->mat[ITS_MAT_L];
-        const int n = L.n_rows;
-        std::vector<int> Lp(n + 1), Lc((size_t)L.nnz);
-        HIPCHK(h, hipMemcpy(Lp.data(), L.row_ptr, (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost));
-        if (L.nnz) HIPCHK(h, hipMemcpy(Lc.data(), L.col, (size_t)L.nnz * sizeof(int), hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; ++i) for (int k = Lp[i]; k < Lp[i + 1]; ++k)
-            if (Lc[k] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
-        int rc = build_levels(h, n, Lp.data(), Lc.data());
+        const int n = h->mat[ITS_MAT_L].n_rows;
+        for (int i = 0; i < n; ++i)
+            if (h->L_maxcol[i] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
+        int rc = build_levels(h, n);
         if (rc) return rc;
     }
     int rc = sweep(h, x_dev, rhs_dev);

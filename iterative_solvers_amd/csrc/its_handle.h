@@ -78,6 +78,9 @@ struct its_handle {
     int4 *sweep_desc = nullptr;                  // device, all such levels back to back
     std::vector<int> level_desc_first, level_desc_count;   // per level; count 0 = level-list kernel
     int sweep_stream = 1;                        // option "sweep_stream": 0 = level-list kernel for every level
+    // host image of crs_L's row structure, kept at upload so that the schedule needs no copy back from the device:
+    // row_ptr and, per row, the largest owned column (-1: none)
+    std::vector<int> L_rp, L_maxcol;
     int *level_rows = nullptr;            // device
     int n_levels = 0;
     // multicolour permutation (gs_order == ITS_GS_MULTICOLOR): new index -> old index

@@ -1,0 +1,25 @@
+// its_hostplan.h — host-side set-up passes of libits_hip.so that run OpenMP-parallel (its_host.cpp, compiled by
+// g++ -fopenmp): everything an upload has to derive from the caller's CRS arrays on the host (keep
+// construction off the serial host path).  Results are independent of the thread count.
+#pragma once
+#include <stdint.h>
+
+namespace its_host {
+
+// monotone row_ptr and columns inside [0, n_cols): 0 ok, 1 row_ptr not monotone, 2 column out of range
+int validate_crs(int n_rows, int n_cols, int64_t nnz, const int *rp, const int *col);
+// column-offset dictionary: cidx[k] = index of col[k] - row(k) in dict (first-occurrence order), n_off = entries used;
+// returns false (n_off = 0) when there are more than 256 distinct offsets
+bool offset_dict(int n_rows, const int *rp, const int *col, unsigned char *cidx, int *dict256, int *n_off);
+// value dictionary over the fp64 bit patterns, same rules
+bool value_dict(int64_t nnz, const double *val, unsigned char *vidx, double *dict256, int *n_vals);
+// longest row of every block of a stream plan (blk[nb + 1] row cuts)
+void block_longest(int nb, const int *blk, const int *rp, int *longest);
+// longest row of the matrix; count, column sum and value hash of the entries right of the diagonal
+void row_stats(int n_rows, const int *rp, const int *col, const double *val, bool upper, int *max_row_len,
+               int64_t *n_upper, int64_t *upper_col_sum, uint64_t *upper_val_xor);
+
+// largest column below `limit` of every row (-1: none): what the sweep schedule and the strictly-lower check need
+void row_maxcol(int n_rows, const int *rp, const int *col, int limit, int *maxcol);
+
+}  // namespace its_host

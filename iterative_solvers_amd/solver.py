@@ -151,21 +151,35 @@ class Solver:
 
     # allocate_cpu_solver_structs + convert_to_crs + extract_diag (main.cpp:206-229,268)
     def upload(self, row_ptr, col, val, b, x0):
+        import time
+        t = [time.perf_counter()]
+        self.setup_times = {}
+
+        def lap(name):
+            t.append(time.perf_counter()); self.setup_times[name] = t[-1] - t[-2]
+
         n = self.n = len(row_ptr) - 1
         if self.solver_type == "gauss-seidel" and self.gs_order == capi.GS_MULTICOLOR:
             # multicolour sweep = the reference's natural-order sweep on P A P^T with rows ordered
             # colour by colour (include/its_hip.h, "Gauss-Seidel ordering helpers")
             self.perm, self.n_colors = capi.multicolor_order(row_ptr, col)
+            lap("multicolor_order")
             row_ptr, col, val = capi.permute_crs(row_ptr, col, val, self.perm)
             b = np.asarray(b)[self.perm]; x0 = np.asarray(x0)[self.perm]
+            lap("permute_crs")
         self.handle.upload_crs(row_ptr, col, val, capi.MAT_A, self.spmv_format)
+        lap("upload_A")
         need_L = self.solver_type == "gauss-seidel" or (self.solver_type == "gmres" and self.preconditioner_type == "gauss-seidel")
         if need_L:                                                     # gauss_seidel.hpp:249-630
-            (Lp, Lc, Lv), (Up, Uc, Uv) = split_L_U(n, row_ptr, col, val)
+            (Lp, Lc, Lv), (Up, Uc, Uv) = capi.split_lu(row_ptr, col, val)      # OpenMP host pass of the library
+            lap("split_L_U")
             self.handle.upload_crs(Lp, Lc, Lv, capi.MAT_L, capi.FMT_CSR_EXACT)
             self.handle.upload_crs(Up, Uc, Uv, capi.MAT_U, capi.FMT_CSR_EXACT)
-        D = extract_diag(n, row_ptr, col, val)
+            lap("upload_L_U")
+        D = capi.extract_diag(row_ptr, col, val)
+        lap("extract_diag")
         self.handle.upload_vectors(D, b, x0)
+        lap("upload_vectors")
 
     def init_residual(self):                                           # solver.hpp:838-855
         return self.handle.init_residual()
