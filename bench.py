@@ -102,6 +102,90 @@ def cpu_baseline(rp, col, val, n, budget_s=15.0):
                       f"on the same {n}-row system, oracle/libits_oracle.so with {threads} OpenMP threads"}
 
 
+GATHER_PEAK = 56.5e9      # random 8-byte gathers/s from an 80 MB table (Infinity Cache resident, not L2): measured ceiling
+                          # of MI355X, independent of occupancy and unrolling (tools/gatherlab.hip, profiles/r02_gatherlab.txt)
+
+
+def other_configs(capi, matgen, S):
+    """BASELINE.json configs[2] (restarted GMRES(50), nonsymmetric 27-pt convection-diffusion 128^3) and configs[3]
+    (Jacobi + multicolour Gauss-Seidel on the 10 M-row power-law matrix) through the same loop body as the headline
+    (its_iterate with the per-trip read-back), each priced with SURVEY.md §8d's algorithmic bytes against the 8 TB/s
+    HBM peak; the power-law legs also against what bounds them, the random-gather rate."""
+    res = {}
+    # ---- C3
+    t0 = time.time()
+    rp, col, val = matgen.convdiff3d_27pt(128)
+    n, nnz = len(rp) - 1, len(col)
+    args = S.Args("gmres", S.LoopParams(max_iters=10**9, tol=0.0, gmres_restart_len=50))
+    sol = S.Solver("gmres", device=0)
+    S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+    setup = time.time() - t0
+    h = sol.handle
+    it = 0
+
+    def cycle(trips):
+        nonlocal it
+        for _ in range(trips):
+            h.iterate(it)
+            if (it + 1) % 50 == 0:
+                h.gmres_restart(it)
+            it += 1
+    cycle(50)                                      # one restart cycle as warm-up, two as the timed region
+    h.synchronize()
+    t0 = time.perf_counter()
+    cycle(100)
+    h.synchronize()
+    dt = (time.perf_counter() - t0) / 100
+    by = spmv_bytes(n, nnz) + float(np.mean([(5 * (k + 1) + 3) * 8 * n for k in range(50)]))
+    res["c3_gmres50_convdiff27_128"] = {
+        "workload": "restarted GMRES(50), 27-pt convection-diffusion 128^3, MGS Arnoldi on device, Givens on host",
+        "rows": n, "nnz": nnz, "ms_per_trip": dt * 1e3, "trips_per_s": 1 / dt, "algorithmic_bytes_per_trip": by,
+        "GBps_algorithmic": by / dt / 1e9, "frac_hbm_peak": by / dt / 1e9 / HBM_PEAK_GBS, "setup_seconds": setup}
+    h.close()
+    del rp, col, val
+    # ---- C4
+    t0 = time.time()
+    rp, col, val = matgen.powerlaw(10_000_000)
+    n, nnz = len(rp) - 1, len(col)
+    gen = time.time() - t0
+    b = np.ones(n)
+    for name, kw in (("jacobi", dict(jacobi_mode=capi.JACOBI_REF)), ("gauss-seidel", dict(gs_order=capi.GS_MULTICOLOR))):
+        args = S.Args(name, S.LoopParams(max_iters=10**9, tol=0.0))
+        sol = S.Solver(name, device=0, **kw)
+        t0 = time.time()
+        S.preprocessing_crs(args, sol, rp, col, val, b, b.copy())
+        setup = time.time() - t0
+        h = sol.handle
+        k = 0
+        for _ in range(5):
+            h.iterate(k); k += 1
+        h.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            h.iterate(k); k += 1
+        h.synchronize()
+        dt = (time.perf_counter() - t0) / 30
+        # the reference's trip = sweep + recorded residual (a second product); gathers per trip: one per entry and pass
+        by = 2 * spmv_bytes(n, nnz) + (16 * n if name == "jacobi" else 40 * n)
+        gathers = nnz if name == "jacobi" else 2 * nnz           # Jacobi: one fused pass over A; GS: U + L, then A
+        res["c4_powerlaw_" + name.replace("-", "_")] = {
+            "workload": f"{name} on the power-law matrix (10 M rows, {nnz} entries, longest row {int(np.diff(rp).max())})"
+                        + (f", multicolour sweep with {sol.n_colors} colours" if sol.n_colors else ", correct sweep fused with the residual pass"),
+            "ms_per_trip": dt * 1e3, "trips_per_s": 1 / dt, "algorithmic_bytes_per_trip": by,
+            "GBps_algorithmic": by / dt / 1e9, "frac_hbm_peak": by / dt / 1e9 / HBM_PEAK_GBS,
+            "bound": "random gathers of x (80 MB: Infinity Cache, not L2)", "gathers_per_trip": gathers,
+            "frac_gather_peak": gathers / dt / GATHER_PEAK, "setup_seconds": setup, "generate_seconds": gen}
+        if name == "jacobi":
+            xd = h.to_dev(np.ones(n)); yd = h.dev_alloc(8 * n)
+            h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=3)
+            ms = h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=20)
+            res["c4_powerlaw_spmv_exact"] = {"ms": ms, "GBps_algorithmic": spmv_bytes(n, nnz) / ms / 1e6,
+                                             "frac_hbm_peak": spmv_bytes(n, nnz) / ms / 1e6 / HBM_PEAK_GBS,
+                                             "frac_gather_peak": nnz / (ms * 1e-3) / GATHER_PEAK}
+        h.close()
+    return res
+
+
 def spawn_ranks(n_ranks, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (rank r -> GPU r), each with
     the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* variables torch.distributed.run would set, relay rank 0's one
@@ -159,6 +243,7 @@ def main():
     ap.add_argument("--format", default="exact", choices=["exact", "vector", "sell"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 (GMRES(50) 27-pt 128^3) and C4 (power-law 10 M rows) legs")
     ap.add_argument("--print-source-hash", action="store_true", help="print the kernel-source hash PMC summaries are stamped with")
     a = ap.parse_args()
     if a.print_source_hash:
@@ -186,6 +271,7 @@ def main():
     N = a.grid
 
     t_gen = time.time()
+    t_matgen = None
     # rehearsal of the N > 1 path on a one-GPU box: ITS_BENCH_TRANSPORT=host puts every rank on GPU 0 and
     # moves halo entries / scalars through the TCP rendezvous instead of RCCL (never a reported number)
     host_transport = os.environ.get("ITS_BENCH_TRANSPORT", "rccl") == "host"
@@ -202,6 +288,7 @@ def main():
         rp, col, val = matgen.laplace3d_7pt(N)
         n = len(rp) - 1
         nnz = len(col)
+        t_matgen = time.time() - t_gen
         args = S.Args("conjugate-gradient", S.LoopParams(max_iters=10**9, tol=0.0))
         S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
     else:
@@ -315,7 +402,9 @@ def main():
             "cg_GBps_streamed": ((roof["streamed_bytes"] + 64 * n) * its_per_s / 1e9) if roof else None,
             "async_loop_ms_per_step": async_ms,
             "last_residual": float(res[-1]),
-            "spmv": spmv_all, "setup_seconds": t_gen,
+            "spmv": spmv_all,
+            # matrix generation (numpy) apart from what the library needs: upload, plans, ELL image, first residual
+            "generate_seconds": t_matgen, "setup_seconds": (t_gen - t_matgen) if t_matgen is not None else t_gen,
             "opt_in": opt_in, "roofline": roof, "cpu_baseline": cpu,
         }
     # second solver of BASELINE.json configs[4] ("CG + Jacobi"): the reference's correct Jacobi sweep
@@ -339,10 +428,15 @@ def main():
         jb = spmv_bytes(n, nnz) + 8 * n
         out["jacobi"] = {"value": a.steps / jdt * world, "unit": out["unit"], "ms_per_step": jdt / a.steps * 1e3,
                          "GBps_algorithmic_per_gpu": jb * a.steps / jdt / 1e9}
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
     h.close()
+    if rank == 0:
+        if world == 1 and not force_dist and not a.no_extra and N == 256:
+            # BASELINE.json configs[2] and configs[3] on the same GPU, as sub-objects (never `value`)
+            del rp, col, val
+            out["configs"] = other_configs(capi, matgen, S)
+        print(json.dumps(out), flush=True)
     rdzv.close()
 
 
