@@ -140,6 +140,46 @@ def c4(small):
         sol.handle.close()
 
 
+def f4(small):
+    """Opt-in communication-reducing variants on one GPU: what the extra vector traffic of
+    pipelined CG and the batched CGS-2 orthogonalisation cost per trip when there is no all-reduce to save."""
+    N = 64 if small else 256
+    rp, col, val = matgen.laplace3d_7pt(N)
+    n = len(rp) - 1
+    for variant in (0, 1):
+        args = S.Args("conjugate-gradient", S.LoopParams(max_iters=10**9, tol=0.0))
+        sol = S.Solver("conjugate-gradient", device=0)
+        sol.handle.set_option("cg_variant", variant)
+        S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+        dt, it = time_trips(sol.handle, 0, 20)
+        dt, it = time_trips(sol.handle, it, 200)
+        emit(config="CG 7-pt %d^3" % N, what="pipelined CG (cg_variant 1)" if variant else "reference CG", ms_per_trip=dt * 1e3,
+             reductions_per_trip=1 if variant else 2)
+        sol.handle.close()
+    del rp, col, val
+    N = 48 if small else 128
+    rp, col, val = matgen.convdiff3d_27pt(N)
+    n = len(rp) - 1
+    for variant in (0, 1):
+        args = S.Args("gmres", S.LoopParams(max_iters=10**9, tol=0.0, gmres_restart_len=50))
+        sol = S.Solver("gmres", device=0)
+        sol.handle.set_option("gmres_ortho", variant)
+        S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+        h = sol.handle
+        it = 0
+        for phase in range(2):
+            h.synchronize(); t0 = time.perf_counter()
+            for _ in range(50 if phase == 0 else 100):
+                h.iterate(it)
+                if (it + 1) % 50 == 0:
+                    h.gmres_restart(it)
+                it += 1
+            h.synchronize(); dt = (time.perf_counter() - t0) / 100
+        emit(config="GMRES(50) 27-pt %d^3" % N, what="CGS-2 (gmres_ortho 1)" if variant else "modified Gram-Schmidt (reference)",
+             ms_per_trip=dt * 1e3, reductions_per_trip="3" if variant else "k + 2 (mean 27.5)")
+        h.close()
+
+
 if __name__ == "__main__":
     small = "--small" in sys.argv
     which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c3", "c4"]
@@ -147,3 +187,5 @@ if __name__ == "__main__":
         c3(small)
     if "c4" in which:
         c4(small)
+    if "f4" in which:
+        f4(small)

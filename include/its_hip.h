@@ -72,6 +72,13 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                      J, Q <- J Q, R = Q H, g = Q beta e1, methods/gmres.hpp:427-658): O(m^3) host
  *                      work per trip, reproduces the reference's |g[k+1]| also BELOW the attainable
  *                      accuracy, where the rotation form keeps shrinking and the dense form stalls.
+ *   "cg_variant"   0 (default) = the reference's CG (methods/cg.hpp:40-281); 1 = pipelined CG (Ghysels-Vanroose): one
+ *                  reduction point per trip instead of two, one fused vector pass — for row-partitioned runs, where a
+ *                  reduction is an all-reduce.  OUTSIDE the parity contract: another recurrence, so another residual
+ *                  history; it converges to the same solution (tests: x within 1e-8, trip count within 5 %).
+ *   "gmres_ortho"  0 (default) = modified Gram-Schmidt (methods/gmres.hpp:269-329), one reduction per basis vector;
+ *                  1 = classical Gram-Schmidt applied twice (CGS-2) with batched dot products: 3 reductions per trip
+ *                  whatever the inner index.  Same standing as cg_variant 1.
  *   "fused_residual" 1 (default) = a Jacobi / Gauss-Seidel trip reads A once: the pass that records
  *                  ||b - A x_new|| (utility_funcs.hpp:423-447) also produces the next trip's product of
  *                  x_new (second in-order chain per row); 0 = separate launches.  Same bits either way.

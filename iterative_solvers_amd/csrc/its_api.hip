@@ -111,6 +111,7 @@ extern "C" int its_destroy(its_handle *h)
     for (auto &A : h->mat) free_csr(A);
     dfree(h->D); dfree(h->b); dfree(h->r); dfree(h->tmp); dfree(h->x_a); dfree(h->x_b); dfree(h->x);
     dfree(h->p); dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
+    dfree(h->pcg_w); dfree(h->pcg_s); dfree(h->pcg_z); dfree(h->pcg_pair[0]); dfree(h->pcg_pair[1]); dfree(h->gram_part); dfree(h->gram_h);
     for (auto &e : h->prof_ev) (void)hipEventDestroy(e);
     for (auto &p : h->part) dfree(p);
     dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows); dfree(h->sweep_desc);
@@ -388,6 +389,18 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
     if (!strcmp(name, "sweep_stream")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_stream: 0 or 1");
         h->sweep_stream = value;
+        return ITS_OK;
+    }
+    if (!strcmp(name, "cg_variant")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "cg_variant: 0 (the reference's CG) or 1 (pipelined CG)");
+        if (h->setup_done && h->solver == ITS_CG) FAIL(h, ITS_ESTATE, "set cg_variant before its_solver_setup");
+        h->cg_variant = value;
+        return ITS_OK;
+    }
+    if (!strcmp(name, "gmres_ortho")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "gmres_ortho: 0 (modified Gram-Schmidt, the reference) or 1 (CGS-2)");
+        if (h->setup_done && h->solver == ITS_GMRES) FAIL(h, ITS_ESTATE, "set gmres_ortho before its_solver_setup");
+        h->gmres_ortho = value;
         return ITS_OK;
     }
     if (!strcmp(name, "readback")) {
@@ -705,6 +718,18 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         h->rr_slot = 0;
         int rc = finish_scalar(h, h->part[0], h->sc + SC_RR0, FIN_SUM);
         if (rc) return rc;
+        if (h->cg_variant == 1) {
+            // pipelined CG: w = A r, s = z = p = 0, and the first pair of sums (r,r), (w,r)
+            dfree(h->pcg_w); dfree(h->pcg_s); dfree(h->pcg_z); dfree(h->pcg_pair[0]); dfree(h->pcg_pair[1]);
+            if (dalloc(h, &h->pcg_w, ne) || dalloc(h, &h->pcg_s, ne) || dalloc(h, &h->pcg_z, ne) ||
+                dalloc(h, &h->pcg_pair[0], 2 * ITS_NPART) || dalloc(h, &h->pcg_pair[1], 2 * ITS_NPART)) return ITS_EHIP;
+            for (double *v : {h->pcg_w, h->pcg_s, h->pcg_z, h->p}) HIPCHK(h, hipMemsetAsync(v, 0, ne * sizeof(double), h->stream));
+            SpmvArgs a; a.x = h->r; a.y = h->pcg_w;
+            if ((rc = solver_spmv(h, a, EPI_STORE))) return rc;
+            launch_pcg_dots(h->r, h->pcg_w, n, h->pcg_pair[0], h->stream);
+            if (its_dist_active(h) && (rc = its_dist_allreduce(h, h->pcg_pair[0], 2 * ITS_NPART, 0))) return rc;
+            h->pcg_trip = 0;
+        }
     } else if (solver_kind == ITS_GMRES) {                           // gmres.hpp:672-786
         if (restart_len < 1) FAIL(h, ITS_EINVAL, "restart_len < 1");
         if (restart_len > (1 << 24)) FAIL(h, ITS_EINVAL, "restart_len beyond 2^24");
@@ -719,6 +744,11 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
             h->Hd.assign((size_t)(m + 1) * m, 0.0); h->Ht = h->Hd; h->Rd = h->Hd;
             h->Qd.assign((size_t)(m + 1) * (m + 1), 0.0); h->Jd = h->Qd; h->Qc = h->Qd;
             for (int i = 0; i <= m; ++i) h->Qd[(size_t)i * (m + 1) + i] = 1.0;
+        }
+        if (h->gmres_ortho == 1) {
+            if (m > 4000) FAIL(h, ITS_EUNSUPPORTED, "gmres_ortho = 1 (CGS-2) keeps the projection coefficients in LDS: restart_len <= 4000");
+            dfree(h->gram_part); dfree(h->gram_h);
+            if (dalloc(h, &h->gram_part, (size_t)(m + 2) * gram_blocks()) || dalloc(h, &h->gram_h, (size_t)2 * (m + 2))) return ITS_EHIP;
         }
         h->restart_count = 0;
         // beta = ||r||, V[0] = r * (1/beta)   (gmres.hpp:734-736,768-771)
@@ -797,6 +827,26 @@ static int trip_cg(its_handle *h, double *res_out)
     if ((rc = allreduce_partials(h, h->part[1], 0))) return rc;       // r.r over all ranks
     launch_cg_update_xp(h->x_a, h->p, h->r, n, h->part[1], 0, rr_in, rr_out, h->sc, res_out, h->stream);
     h->rr_slot ^= 1;
+    HIPCHK(h, hipGetLastError());
+    return ITS_OK;
+}
+
+// One trip of pipelined CG ("cg_variant" 1; its_krylov_cr.hip): q = A w, then ONE fused vector pass, then ONE
+// reduction point (the pair of partial arrays is all-reduced together when row-partitioned).  The recorded value is
+// ||r_new||_2 as in the reference loop (utility_funcs.hpp:483).
+static int trip_cg_pipelined(its_handle *h, double *res_out)
+{
+    const int n = h->n;
+    const int par = h->pcg_trip & 1;
+    SpmvArgs a; a.x = h->pcg_w; a.y = h->tmp;
+    int rc = solver_spmv(h, a, EPI_STORE);
+    if (rc) return rc;
+    double *sc_in = h->sc + (par ? SC_PCG1 : SC_PCG0), *sc_out = h->sc + (par ? SC_PCG0 : SC_PCG1);
+    launch_pcg_update(h->x_a, h->r, h->pcg_w, h->p, h->pcg_s, h->pcg_z, h->tmp, n, h->pcg_pair[par], h->pcg_pair[par ^ 1],
+                      sc_in, sc_out, h->pcg_trip == 0, h->stream);
+    if (its_dist_active(h) && (rc = its_dist_allreduce(h, h->pcg_pair[par ^ 1], 2 * ITS_NPART, 0))) return rc;
+    launch_reduce_finalize(h->pcg_pair[par ^ 1], res_out, FIN_SQRT, h->stream);
+    ++h->pcg_trip;
     HIPCHK(h, hipGetLastError());
     return ITS_OK;
 }
@@ -887,8 +937,24 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     const bool hcol_pinned = !use_copy;
     double *hcol_out = hcol_pinned ? h->pinned + h->pin_h : h->hcol_dev;
     if (hcol_pinned) arm_pinned_word(hcol_out + (k + 1));
-    // MGS (gmres.hpp:269-329): step j finishes w -= h_{j-1} v_{j-1} and starts h_j = w . v_j
     const double *prev_part = nullptr; int prev_scalar = 0;
+    if (h->gmres_ortho == 1) {
+        // CGS-2 ("gmres_ortho" 1): h1 = V^T w, w -= V h1, h2 = V^T w, w -= V h2, H[:,k] = h1 + h2 — every product
+        // batched over j, one reduction per pass and one for ||w||: 3 per trip instead of k + 2
+        const int nv = k + 1;
+        double *h1 = h->gram_h, *h2 = h->gram_h + (m + 2);
+        for (int pass = 0; pass < 2; ++pass) {
+            double *hp = pass ? h2 : h1;
+            launch_gram_dots(w, h->V, (int64_t)ld, nv, n, h->gram_part, h->stream);
+            launch_gram_finalize(h->gram_part, nv, hp, h->stream);
+            if (its_dist_active(h) && (rc = its_dist_allreduce(h, hp, nv, 0))) return rc;
+            launch_gram_axpy(w, h->V, (int64_t)ld, nv, hp, n, pass ? h->part[0] : nullptr, h->stream);
+        }
+        launch_gram_combine(h1, h2, nv, hcol_out, h->stream);
+        if ((rc = allreduce_partials(h, h->part[0], 0))) return rc;
+        prev_part = h->part[0];
+    } else
+    // MGS (gmres.hpp:269-329): step j finishes w -= h_{j-1} v_{j-1} and starts h_j = w . v_j
     for (int j = 0; j <= k + 1; ++j) {
         double *next_part = h->part[j & 1];
         const double *v_prev = j > 0 ? h->V + (size_t)(j - 1) * ld : nullptr;
@@ -1010,7 +1076,7 @@ extern "C" int its_iterate(its_handle *h, int iter_count, double *residual_norm)
     double *slot = h->pinned + PIN_RES;
     double *res = use_copy ? h->sc + SC_RES : slot;
     if (!use_copy) arm_pinned_word(slot);
-    if (h->solver == ITS_CG) rc = trip_cg(h, res);
+    if (h->solver == ITS_CG) rc = h->cg_variant == 1 ? trip_cg_pipelined(h, res) : trip_cg(h, res);
     else if (h->solver == ITS_JACOBI) rc = trip_jacobi(h, res);
     else rc = trip_gs(h, res);
     if (rc) return rc;
@@ -1055,7 +1121,7 @@ extern "C" int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double
     }
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     for (int i = 0; i < n_trips; ++i) {
-        if (h->solver == ITS_CG) rc = trip_cg(h, h->res_dev + i);
+        if (h->solver == ITS_CG) rc = h->cg_variant == 1 ? trip_cg_pipelined(h, h->res_dev + i) : trip_cg(h, h->res_dev + i);
         else if (h->solver == ITS_JACOBI) rc = trip_jacobi(h, h->res_dev + i);
         else rc = trip_gs(h, h->res_dev + i);
         if (rc) return rc;
@@ -1137,7 +1203,10 @@ extern "C" int its_final_residual(its_handle *h, double *residual_norm)
     if (!residual_norm) return ITS_EINVAL;
     if (h->solver == ITS_GMRES) { *residual_norm = h->last_residual; return ITS_OK; }
     double *res = h->sc + SC_RES;
-    if (h->solver == ITS_CG) {
+    if (h->solver == ITS_CG && h->cg_variant == 1) {
+        // the same quirk as below, kept: the norm of the residual BEFORE the last trip = sqrt(gamma) that trip read
+        launch_sqrt_scalar(h->sc + ((h->pcg_trip & 1) ? SC_PCG1 : SC_PCG0), res, h->stream);
+    } else if (h->solver == ITS_CG) {
         // Solver::r after iterate's swap and exchange_arrays' swap (solver.hpp:545,833) is the
         // buffer that held r_old during the last trip, i.e. the PREVIOUS trip's residual.  The
         // device keeps one r; the previous norm is sqrt(rr_old) which still sits in the other slot.

@@ -116,7 +116,7 @@ static int ensure_plan(its_handle *h)
         HIPCHK(h, hipStreamCreateWithPriority(&h->dist->cstream, hipStreamNonBlocking, prio_greatest));
         HIPCHK(h, hipEventCreateWithFlags(&h->dist->ev_pack, hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->dist->ev_halo, hipEventDisableTiming));
-        HIPCHK(h, hipHostMalloc((void **)&h->dist->host_sc, ITS_NPART * sizeof(double), hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void **)&h->dist->host_sc, 2 * ITS_NPART * sizeof(double), hipHostMallocDefault));
     }
     return ITS_OK;
 }
@@ -436,7 +436,7 @@ int its_dist_allreduce(its_handle *h, double *dev, int count, int op)
         NCCLCHK(h, ncclAllReduce(dev, dev, count, ncclDouble, op ? ncclMax : ncclSum, d->comm_red, h->stream));
         return ITS_OK;
     }
-    if (count > ITS_NPART) FAIL(h, ITS_EINVAL, "host all-reduce limited to ITS_NPART values");
+    if (count > 2 * ITS_NPART) FAIL(h, ITS_EINVAL, "host all-reduce limited to 2 ITS_NPART values");
     HIPCHK(h, hipMemcpyAsync(d->host_sc, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (d->rcb(d->user, d->host_sc, count, op) != 0) FAIL(h, ITS_ECOMM, "host all-reduce callback failed");

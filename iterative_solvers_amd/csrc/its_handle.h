@@ -45,6 +45,12 @@ struct its_handle {
     // dense least-squares state of the reference formulation (gmres_givens == 1)
     std::vector<double> Hd, Qd, Jd, Qc, Ht, Rd;
     int gmres_givens = 0;                 // 0: O(m) rotation updates, 1: the reference's dense products
+    // communication-reducing variants (its_krylov_cr.hip), opt-in: "cg_variant" 1 = pipelined CG, "gmres_ortho" 1 = CGS-2
+    int cg_variant = 0, gmres_ortho = 0;
+    double *pcg_w = nullptr, *pcg_s = nullptr, *pcg_z = nullptr;     // pipelined CG: w = A r, s = A p, z = A s
+    double *pcg_pair[2] = {nullptr, nullptr};                        // (r,r) and (w,r) partials, double-buffered by trip parity
+    int pcg_trip = 0;
+    double *gram_part = nullptr, *gram_h = nullptr;                  // CGS-2: batched-dot partials, h of both passes
     // reductions / scalars
     double *part[4] = {nullptr, nullptr, nullptr, nullptr};
     double *sc = nullptr;                 // SC_COUNT device scalars

@@ -164,6 +164,19 @@ void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t
                            const double *y_dev, int m, int64_t n, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
+// Communication-reducing variants (its_krylov_cr.hip; opt-in, outside the parity contract)
+// ---------------------------------------------------------------------------------------
+enum { SC_PCG0 = 8, SC_PCG1 = 11 };        // two triples {gamma_old, alpha_old, beta} of pipelined CG, by trip parity
+void launch_pcg_dots(const double *r, const double *w, int64_t n, double *pair, hipStream_t s);   // pair: 2 x ITS_NPART
+void launch_pcg_update(double *x, double *r, double *w, double *p, double *sv, double *z, const double *q, int64_t n,
+                       const double *pair_in, double *pair_out, const double *sc_in, double *sc_out, int first, hipStream_t s);
+int gram_blocks();                         // partials per basis vector of launch_gram_dots
+void launch_gram_dots(const double *w, const double *V, int64_t ld, int nv, int64_t n, double *part, hipStream_t s);
+void launch_gram_finalize(const double *part, int nv, double *h, hipStream_t s);
+void launch_gram_axpy(double *w, const double *V, int64_t ld, int nv, const double *h, int64_t n, double *part_ww, hipStream_t s);
+void launch_gram_combine(const double *h1, const double *h2, int nv, double *hcol, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // Gauss-Seidel / triangular sweeps (kernels.hpp:451-473) by dependency level or colour.
 // rows[] lists the rows of one level; x[i] = (rhs[i] - sum_j L_ij x_j) / D[i], in-order fma.
 // ---------------------------------------------------------------------------------------

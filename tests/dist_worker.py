@@ -52,6 +52,9 @@ def main():
         owned = cp.owned_global
     else:
         plan = D.upload_slab(h, rdzv, n_global, row_begin, rp, colg, val, capi.FMT_CSR_EXACT)
+    for kv in filter(None, os.environ.get("ITS_TEST_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        h.set_option(k, int(v))
     h.upload_vectors(diag, np.ones(n_loc), np.ones(n_loc))
     r0_inf, r0_two = h.init_residual()
     kindmap = {"cg": capi.CG, "jacobi": capi.JACOBI, "gmres": capi.GMRES, "gs": capi.GAUSS_SEIDEL, "gmres_pgs": capi.GMRES}
