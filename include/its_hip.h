@@ -33,8 +33,13 @@ enum { ITS_PRECOND_NONE = 0, ITS_PRECOND_JACOBI = 1, ITS_PRECOND_GS = 2 };
  *   ITS_FMT_CSR_EXACT : one lane per row, in-order fused multiply-add from 0 — bit-identical
  *                       to spmv_crs_cpu (kernels.hpp:380-409); col/val streamed through LDS.
  *   ITS_FMT_CSR_VECTOR: 2^k lanes per row chosen from the row-length histogram; 1e-12 rel.
- *   ITS_FMT_SELL      : SELL-64-sigma; 1e-12 rel.                                         */
-enum { ITS_FMT_CSR_EXACT = 0, ITS_FMT_CSR_VECTOR = 1, ITS_FMT_SELL = 2 };
+ *   ITS_FMT_SELL      : SELL-64-sigma; 1e-12 rel.
+ *   ITS_FMT_MIXED     : mixed precision storage in the spirit of the reference's USE_AP "ap[dp_sp]" mode (main.cpp:171-184,
+ *                       config.mk:56-63: entries split by a magnitude threshold): entries with |a_ij| >= threshold
+ *                       (its_set_mixed_threshold) stay fp64, the others are STORED in fp32; x, y and the accumulation
+ *                       stay fp64.  Opt-in, not bit-exact: per row |error| <= 2^-24 sum over the fp32 entries of
+ *                       |a_ij x_j| (+ the reordering error of the vector variant).  8 instead of 12 bytes per fp32 entry. */
+enum { ITS_FMT_CSR_EXACT = 0, ITS_FMT_CSR_VECTOR = 1, ITS_FMT_SELL = 2, ITS_FMT_MIXED = 3 };
 /* which matrix of SparseMtxFormat<VT> (sparse_matrix.hpp:352-394) an upload fills */
 enum { ITS_MAT_A = 0, ITS_MAT_L = 1, ITS_MAT_U = 2 };
 /* Gauss-Seidel sweep order.  The library always executes the reference's forward substitution
@@ -57,6 +62,12 @@ const char *its_version(void);
  * (methods/gauss_seidel.hpp:433-450).  Builds the row-block plan / SELL image on the host. */
 int its_upload_crs(its_handle *h, int which, int n_rows, int n_cols, int64_t nnz,
                    const int *row_ptr, const int *col, const double *val, int format);
+/* magnitude threshold of ITS_FMT_MIXED uploads that follow (AP_THRESHOLD_1 of config.mk:59): entries below it are
+ * stored in fp32.  Default 1.0; threshold <= 0 keeps everything fp64, +inf stores everything in fp32. */
+int its_set_mixed_threshold(its_handle *h, double threshold);
+/* entries kept in fp64 / stored in fp32 by the last ITS_FMT_MIXED upload of this matrix (dp_percent / sp_percent of
+ * main.cpp:186-190) */
+int its_mixed_info(its_handle *h, int which, int64_t *nnz_fp64, int64_t *nnz_fp32);
 /* after extract_diag + generate_vector + scale_vector (main.cpp:268-276): D, b, x_old. */
 int its_upload_vectors(its_handle *h, const double *D, const double *b, const double *x0, int n);
 /* Solver::init_residual (solver.hpp:838-855) + both norms that

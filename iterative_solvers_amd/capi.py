@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libits_hip.so")
 JACOBI, GAUSS_SEIDEL, CG, GMRES = 0, 1, 2, 3
 JACOBI_SHIPPED, JACOBI_REF = 0, 1
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_GS = 0, 1, 2
-FMT_CSR_EXACT, FMT_CSR_VECTOR, FMT_SELL = 0, 1, 2
+FMT_CSR_EXACT, FMT_CSR_VECTOR, FMT_SELL, FMT_MIXED = 0, 1, 2, 3
 MAT_A, MAT_L, MAT_U = 0, 1, 2
 GS_LEVEL, GS_MULTICOLOR = 0, 1
 
@@ -33,6 +33,8 @@ SIGNATURES = {
     "its_last_error": (C.c_char_p, [C.c_void_p]),
     "its_version": (C.c_char_p, []),
     "its_upload_crs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "its_set_mixed_threshold": (C.c_int, [C.c_void_p, C.c_double]),
+    "its_mixed_info": (C.c_int, [C.c_void_p, C.c_int, _c_i64_p, _c_i64_p]),
     "its_upload_vectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "its_init_residual": (C.c_int, [C.c_void_p, _c_dbl_p, _c_dbl_p]),
     "its_solver_setup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -184,6 +186,14 @@ class Handle:
         n = len(row_ptr) - 1
         self.check(self.L.its_upload_crs(self.h, which, n, n if n_cols is None else n_cols, len(col),
                                          _ptr(row_ptr), _ptr(col), _ptr(val), fmt), "its_upload_crs")
+
+    def set_mixed_threshold(self, thr: float):
+        self.check(self.L.its_set_mixed_threshold(self.h, float(thr)), "its_set_mixed_threshold")
+
+    def mixed_info(self, which=MAT_A):
+        a, b = C.c_int64(), C.c_int64()
+        self.check(self.L.its_mixed_info(self.h, which, C.byref(a), C.byref(b)), "its_mixed_info")
+        return a.value, b.value
 
     def upload_vectors(self, D, b, x0):
         D = np.ascontiguousarray(D, dtype=np.float64)

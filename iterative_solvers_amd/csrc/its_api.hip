@@ -40,6 +40,7 @@ static void free_csr(CsrDev &A)
     dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc); dfree(A.blk_desc_big);
     dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict); dfree(A.vidx); dfree(A.val_dict);
     dfree(A.ell_val); dfree(A.ell_idx);
+    dfree(A.mix_rp_d); dfree(A.mix_col_d); dfree(A.mix_val_d); dfree(A.mix_rp_s); dfree(A.mix_col_s); dfree(A.mix_val_s);
     A = CsrDev();
 }
 
@@ -330,6 +331,26 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     A.lanes_per_row = pick_lanes_per_row(n_rows, nnz, A.max_row_len);
     pt.lap("stream plans + statistics");
     if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; pt.lap("SELL image"); }
+    if (format == ITS_FMT_MIXED) {
+        std::vector<int> rpd((size_t)n_rows + 1), rps((size_t)n_rows + 1), cd((size_t)std::max<int64_t>(nnz, 1)), cs((size_t)std::max<int64_t>(nnz, 1));
+        std::vector<double> vd((size_t)std::max<int64_t>(nnz, 1));
+        std::vector<float> vs((size_t)std::max<int64_t>(nnz, 1));
+        its_host::split_by_magnitude(n_rows, row_ptr, col, val, h->mixed_threshold, rpd.data(), cd.data(), vd.data(), rps.data(), cs.data(), vs.data());
+        A.mix_nnz_d = rpd[n_rows]; A.mix_nnz_s = rps[n_rows];
+        if (dalloc(h, &A.mix_rp_d, (size_t)n_rows + 1) || dalloc(h, &A.mix_rp_s, (size_t)n_rows + 1) || dalloc(h, &A.mix_col_d, (size_t)A.mix_nnz_d) ||
+            dalloc(h, &A.mix_val_d, (size_t)A.mix_nnz_d) || dalloc(h, &A.mix_col_s, (size_t)A.mix_nnz_s) || dalloc(h, &A.mix_val_s, (size_t)A.mix_nnz_s)) return ITS_EHIP;
+        HIPCHK(h, hipMemcpy(A.mix_rp_d, rpd.data(), ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(A.mix_rp_s, rps.data(), ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
+        if (A.mix_nnz_d) {
+            HIPCHK(h, hipMemcpy(A.mix_col_d, cd.data(), (size_t)A.mix_nnz_d * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(A.mix_val_d, vd.data(), (size_t)A.mix_nnz_d * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (A.mix_nnz_s) {
+            HIPCHK(h, hipMemcpy(A.mix_col_s, cs.data(), (size_t)A.mix_nnz_s * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(A.mix_val_s, vs.data(), (size_t)A.mix_nnz_s * sizeof(float), hipMemcpyHostToDevice));
+        }
+        pt.lap("mixed-precision image");
+    }
     // sliced ELL image for short regular rows (its_ell.hip), built on the device from the arrays just uploaded
     if (A.n_off >= 1 && A.n_off <= ELL_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELL_MAX_W && n_rows > 0 &&
         getenv("ITS_NO_ELL") == nullptr) {
@@ -366,10 +387,27 @@ extern "C" int its_upload_crs(its_handle *h, int which, int n_rows, int n_cols, 
                               const int *row_ptr, const int *col, const double *val, int format)
 {
     if (!h) return ITS_EINVAL;
-    if (format < ITS_FMT_CSR_EXACT || format > ITS_FMT_SELL) FAIL(h, ITS_EINVAL, "unknown format");
+    if (format < ITS_FMT_CSR_EXACT || format > ITS_FMT_MIXED) FAIL(h, ITS_EINVAL, "unknown format");
     int rc = its_upload_csr_local(h, which, n_rows, n_cols, nnz, row_ptr, col, val, format);
     if (rc == ITS_OK && which == ITS_MAT_A) { h->n = n_rows; h->n_ext = n_cols; }
     return rc;
+}
+
+extern "C" int its_set_mixed_threshold(its_handle *h, double threshold)
+{
+    if (!h) return ITS_EINVAL;
+    if (threshold != threshold) FAIL(h, ITS_EINVAL, "threshold is NaN");
+    h->mixed_threshold = threshold;
+    return ITS_OK;
+}
+
+extern "C" int its_mixed_info(its_handle *h, int which, int64_t *nnz_fp64, int64_t *nnz_fp32)
+{
+    if (!h || which < 0 || which > 2) return ITS_EINVAL;
+    if (!h->have[which] || !h->mat[which].mix_rp_d) FAIL(h, ITS_ESTATE, "matrix was not uploaded with ITS_FMT_MIXED");
+    if (nnz_fp64) *nnz_fp64 = h->mat[which].mix_nnz_d;
+    if (nnz_fp32) *nnz_fp32 = h->mat[which].mix_nnz_s;
+    return ITS_OK;
 }
 
 extern "C" int its_set_option(its_handle *h, const char *name, int value)
@@ -455,6 +493,9 @@ static int spmv_dispatch(its_handle *h, const CsrDev &A, const SpmvArgs &a, int 
     else if (format == ITS_FMT_SELL) {
         if (!A.sell_val && A.nnz) FAIL(h, ITS_ESTATE, "matrix was not uploaded with ITS_FMT_SELL");
         launch_spmv_sell(A, a, epi, h->stream);
+    } else if (format == ITS_FMT_MIXED) {
+        if (!A.mix_rp_d) FAIL(h, ITS_ESTATE, "matrix was not uploaded with ITS_FMT_MIXED");
+        launch_spmv_mixed(A, a, epi, h->stream);
     } else FAIL(h, ITS_EINVAL, "unknown format");
     HIPCHK(h, hipGetLastError());
     return ITS_OK;

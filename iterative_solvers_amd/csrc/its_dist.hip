@@ -354,6 +354,14 @@ int its_dist_exchange(its_handle *h, double *x, int color)
     return ITS_OK;
 }
 
+// the formats that are launched over the whole local matrix (no interior / boundary split)
+static void launch_spmv_reordered(its_handle *h, const CsrDev &A, const SpmvArgs &a, int epi)
+{
+    if (h->fmt == ITS_FMT_CSR_VECTOR) launch_spmv_vector(A, a, epi, h->stream);
+    else if (h->fmt == ITS_FMT_MIXED) launch_spmv_mixed(A, a, epi, h->stream);
+    else launch_spmv_sell(A, a, epi, h->stream);
+}
+
 // halo exchange of the vector a.x (length n_loc + n_halo) overlapped with the interior SpMV
 int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
 {
@@ -387,8 +395,7 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
             NCCLCHK(h, ncclGroupEnd());
         }
         if (split) launch_spmv_exact(A, a, epi, h->stream);
-        else if (h->fmt == ITS_FMT_CSR_VECTOR) launch_spmv_vector(A, a, epi, h->stream);
-        else launch_spmv_sell(A, a, epi, h->stream);
+        else launch_spmv_reordered(h, A, a, epi);
     } else if (d->transport == 1) {
         if (d->n_nbr) {
             HIPCHK(h, hipEventRecord(d->ev_pack, h->stream));
@@ -408,8 +415,7 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
             if (nb_bnd) launch_spmv_exact_desc(A, desc_bnd, nb_bnd, a, epi, 1, h->stream);
         } else {
             if (d->n_nbr) HIPCHK(h, hipStreamWaitEvent(h->stream, d->ev_halo, 0));
-            if (h->fmt == ITS_FMT_CSR_VECTOR) launch_spmv_vector(A, a, epi, h->stream);
-            else launch_spmv_sell(A, a, epi, h->stream);
+            launch_spmv_reordered(h, A, a, epi);
         }
     } else {
         // HOST transport (tests): stage through the callbacks; interior blocks are still launched
@@ -421,8 +427,7 @@ int its_dist_spmv(its_handle *h, const SpmvArgs &a, int epi)
             FAIL(h, ITS_ECOMM, "host exchange callback failed");
         if (d->n_halo) HIPCHK(h, hipMemcpyAsync(x + n_loc, d->host_recv, (size_t)d->n_halo * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (split) { if (nb_bnd) launch_spmv_exact_desc(A, desc_bnd, nb_bnd, a, epi, 1, h->stream); }
-        else if (h->fmt == ITS_FMT_CSR_VECTOR) launch_spmv_vector(A, a, epi, h->stream);
-        else launch_spmv_sell(A, a, epi, h->stream);
+        else launch_spmv_reordered(h, A, a, epi);
     }
     HIPCHK(h, hipGetLastError());
     return ITS_OK;

@@ -29,6 +29,7 @@ struct its_handle {
     CsrDev mat[3];
     bool have[3] = {false, false, false};
     int fmt = ITS_FMT_CSR_EXACT;          // format used by the solver loops for A
+    double mixed_threshold = 1.0;         // its_set_mixed_threshold: entries below it are stored in fp32 (ITS_FMT_MIXED)
 
     int n = 0;                            // owned rows
     int n_ext = 0;                        // owned + halo (== n on one GPU)

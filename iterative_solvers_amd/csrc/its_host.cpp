@@ -11,6 +11,7 @@
 #include "its_hostplan.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <numeric>
@@ -194,6 +195,27 @@ void row_maxcol(int n_rows, const int *rp, const int *col, int limit, int *maxco
         int m = -1;
         for (int k = rp[i]; k < rp[i + 1]; ++k) if (col[k] < limit) m = std::max(m, col[k]);
         maxcol[i] = m;
+    }
+}
+
+void split_by_magnitude(int n_rows, const int *rp, const int *col, const double *val, double thr,
+                        int *rp_d, int *col_d, double *val_d, int *rp_s, int *col_s, float *val_s)
+{
+    rp_d[0] = 0; rp_s[0] = 0;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_rows; ++i) {
+        int d = 0;
+        for (int k = rp[i]; k < rp[i + 1]; ++k) d += !(std::abs(val[k]) < thr);        // NaN stays fp64
+        rp_d[i + 1] = d; rp_s[i + 1] = rp[i + 1] - rp[i] - d;
+    }
+    for (int i = 0; i < n_rows; ++i) { rp_d[i + 1] += rp_d[i]; rp_s[i + 1] += rp_s[i]; }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_rows; ++i) {
+        int d = rp_d[i], q = rp_s[i];
+        for (int k = rp[i]; k < rp[i + 1]; ++k) {
+            if (!(std::abs(val[k]) < thr)) { col_d[d] = col[k]; val_d[d] = val[k]; ++d; }
+            else { col_s[q] = col[k]; val_s[q] = (float)val[k]; ++q; }
+        }
     }
 }
 

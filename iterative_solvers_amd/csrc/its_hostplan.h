@@ -22,4 +22,9 @@ void row_stats(int n_rows, const int *rp, const int *col, const double *val, boo
 // largest column below `limit` of every row (-1: none): what the sweep schedule and the strictly-lower check need
 void row_maxcol(int n_rows, const int *rp, const int *col, int limit, int *maxcol);
 
+// split by magnitude (ITS_FMT_MIXED): |val| >= thr -> (rp_d, col_d, val_d), else -> (rp_s, col_s, val_s as float);
+// row pointers n_rows + 1, the other outputs sized nnz; entry order inside a row kept
+void split_by_magnitude(int n_rows, const int *rp, const int *col, const double *val, double thr,
+                        int *rp_d, int *col_d, double *val_d, int *rp_s, int *col_s, float *val_s);
+
 }  // namespace its_host

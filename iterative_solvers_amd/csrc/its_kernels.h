@@ -67,6 +67,12 @@ struct CsrDev {
     double *ell_val = nullptr;
     uint32_t *ell_idx = nullptr;
     int ell_w = 0, ell_blocks = 0, ell_pb = 0;
+    // mixed-precision image (ITS_FMT_MIXED): the entries at or above the threshold as an fp64 CRS, the rest as an
+    // fp32 CRS, both in the row order of the original
+    int *mix_rp_d = nullptr, *mix_col_d = nullptr, *mix_rp_s = nullptr, *mix_col_s = nullptr;
+    double *mix_val_d = nullptr;
+    float *mix_val_s = nullptr;
+    int64_t mix_nnz_d = 0, mix_nnz_s = 0;
     // stream plan
     int n_blocks = 0;
     int4 *blk_desc = nullptr;                 // {first row, rows, first nnz, end nnz} per row block
@@ -120,6 +126,7 @@ void launch_ell_build(const CsrDev &A, hipStream_t s);   // fills ell_val / ell_
 int ell_tune(const char *name, int value);               // "spmv_ell", "spmv_ell_grid", "spmv_ell_nt", "spmv_ell_map"
 void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
+void launch_spmv_mixed(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);   // EPI_STORE (+ dot), EPI_RESIDUAL
 
 // ---------------------------------------------------------------------------------------
 // BLAS-1.  Reductions write ITS_NPART partials; reduce_finalize turns them into one scalar.

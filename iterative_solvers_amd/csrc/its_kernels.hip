@@ -1010,6 +1010,81 @@ void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t
 }
 
 // ======================================================================================
+// SpMV, mixed precision storage (ITS_FMT_MIXED; the reference's USE_AP "ap[dp_sp]" idea, main.cpp:171-184): the
+// entries at or above the threshold as an fp64 CRS, the rest as an fp32 CRS (8 instead of 12 bytes per entry);
+// x, y and the accumulation stay fp64.  LPR lanes per row as in the vector kernel.  Not bit-exact by design.
+// ======================================================================================
+template <int LPR, int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_mixed_kernel(
+    int n_rows, const int *__restrict__ rp_d, const int *__restrict__ col_d, const double *__restrict__ val_d,
+    const int *__restrict__ rp_s, const int *__restrict__ col_s, const float *__restrict__ val_s, SpmvArgs a)
+{
+    __shared__ double s_red[4];
+    constexpr int ROWS_PER_BLOCK = ITS_BLOCK / LPR;
+    const int t = threadIdx.x;
+    const int sub = t & (LPR - 1);
+    const int G = gridDim.x;
+    const int slot = xcd_slot(blockIdx.x, G);
+    const int64_t n_groups = ((int64_t)n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const int64_t g0 = (slot * n_groups) / G, g1 = ((slot + 1) * n_groups) / G;
+    double lane_sum = 0.0, lane_max = 0.0;
+    for (int64_t grp = g0; grp < g1; ++grp) {
+        const int row = (int)(grp * ROWS_PER_BLOCK) + t / LPR;
+        double acc = 0.0;
+        if (row < n_rows) {
+            for (int j = rp_d[row] + sub, j1 = rp_d[row + 1]; j < j1; j += LPR) acc = fma(val_d[j], a.x[col_d[j]], acc);
+            for (int j = rp_s[row] + sub, j1 = rp_s[row + 1]; j < j1; j += LPR) acc = fma((double)val_s[j], a.x[col_s[j]], acc);
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, ITS_WAVE);
+        if (row < n_rows && sub == 0) {
+            if (EPI == EPI_STORE) {
+                a.y[row] = acc;
+                if (DOT) lane_sum = fma(acc, a.dotv[row], lane_sum);
+            } else {
+                const double r = a.b[row] - acc;
+                if (a.y) a.y[row] = r;
+                lane_sum = fma(r, r, lane_sum);
+                lane_max = fmax(lane_max, fabs(r));
+            }
+        }
+    }
+    if (DOT || EPI == EPI_RESIDUAL) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) a.part_sum[blockIdx.x] = bs;
+        if (EPI == EPI_RESIDUAL && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) a.part_max[blockIdx.x] = bm;
+        }
+    }
+}
+
+template <int LPR>
+static void launch_mixed_lpr(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s)
+{
+    dim3 g(ITS_NPART), b(ITS_BLOCK);
+#define ITS_LAUNCHM(E, D) \
+    hipLaunchKernelGGL((spmv_mixed_kernel<LPR, E, D>), g, b, 0, s, A.n_rows, A.mix_rp_d, A.mix_col_d, A.mix_val_d, A.mix_rp_s, \
+                       A.mix_col_s, A.mix_val_s, a)
+    if (epi == EPI_RESIDUAL) ITS_LAUNCHM(EPI_RESIDUAL, false);
+    else if (a.dotv) ITS_LAUNCHM(EPI_STORE, true);
+    else ITS_LAUNCHM(EPI_STORE, false);
+#undef ITS_LAUNCHM
+}
+
+void launch_spmv_mixed(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s)
+{
+    switch (A.lanes_per_row) {
+    case 2: launch_mixed_lpr<2>(A, a, epi, s); break;
+    case 4: launch_mixed_lpr<4>(A, a, epi, s); break;
+    case 8: launch_mixed_lpr<8>(A, a, epi, s); break;
+    case 16: launch_mixed_lpr<16>(A, a, epi, s); break;
+    case 32: launch_mixed_lpr<32>(A, a, epi, s); break;
+    default: launch_mixed_lpr<64>(A, a, epi, s); break;
+    }
+}
+
+// ======================================================================================
 // SpMV, SELL-64-sigma: one wavefront per chunk of 64 (sorted) rows, column-major inside the
 // chunk (values[chunk_ptr + j*64 + lane], CUDA_tests/helpers/utilities.cpp:321-337), so every
 // load is one fully coalesced 512-byte / 256-byte wave access.  perm[] maps chunk row -> row.

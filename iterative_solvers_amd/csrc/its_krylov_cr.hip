@@ -102,17 +102,32 @@ void launch_pcg_update(double *x, double *r, double *w, double *p, double *sv, d
 constexpr int GRAM_BLOCKS = 512;       // workgroups of the batched-dot kernel = partials per j
 constexpr int GRAM_J = 8;              // basis vectors per pass over w inside the kernel
 
-// part[j * GRAM_BLOCKS + block] = this block's share of w . V_j
+// part[j * GRAM_BLOCKS + block] = this block's share of w . V_j.  Two elements per lane (w and the basis vectors are
+// 256-byte aligned, ld is a multiple of 32), GRAM_J basis vectors per pass over w: 8 independent 16-byte loads in
+// flight per lane.
 __global__ __launch_bounds__(ITS_BLOCK) void gram_dots_kernel(const double *__restrict__ w, const double *__restrict__ V,
                                                               int64_t ld, int nv, int64_t n, double *__restrict__ part)
 {
     __shared__ double s_red[4];
     const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x, nth = (int64_t)gridDim.x * ITS_BLOCK;
+    const int64_t n2 = n / 2;
+    const cr_v2d *w2 = reinterpret_cast<const cr_v2d *>(w);
     for (int j0 = 0; j0 < nv; j0 += GRAM_J) {
         double acc[GRAM_J];
 #pragma unroll
         for (int u = 0; u < GRAM_J; ++u) acc[u] = 0.0;
-        for (int64_t i = tid; i < n; i += nth) {
+        for (int64_t i = tid; i < n2; i += nth) {
+            const cr_v2d wv = w2[i];
+            cr_v2d v[GRAM_J];
+#pragma unroll
+            for (int u = 0; u < GRAM_J; ++u) {
+                const int j = j0 + u < nv ? j0 + u : j0;             // clamped: the load is unconditional
+                v[u] = reinterpret_cast<const cr_v2d *>(V + (int64_t)j * ld)[i];
+            }
+#pragma unroll
+            for (int u = 0; u < GRAM_J; ++u) acc[u] = fma(wv.y, v[u].y, fma(wv.x, v[u].x, acc[u]));
+        }
+        for (int64_t i = 2 * n2 + tid; i < n; i += nth) {
             const double wv = w[i];
 #pragma unroll
             for (int u = 0; u < GRAM_J; ++u)
@@ -136,18 +151,36 @@ __global__ __launch_bounds__(ITS_BLOCK) void gram_finalize_kernel(const double *
     if (threadIdx.x == 0) h[blockIdx.x] = t;
 }
 
-// w -= sum_j h[j] V_j; optionally the partial sums of the new w . w
+// w -= sum_j h[j] V_j; optionally the partial sums of the new w . w.  Same access shape as gram_dots_kernel.
 __global__ __launch_bounds__(ITS_BLOCK) void gram_axpy_kernel(double *__restrict__ w, const double *__restrict__ V, int64_t ld,
                                                               int nv, const double *__restrict__ h, int64_t n,
                                                               double *__restrict__ part_ww)
 {
     extern __shared__ double s_h[];
     __shared__ double s_red[4];
-    for (int j = threadIdx.x; j < nv; j += ITS_BLOCK) s_h[j] = h[j];
+    for (int j = threadIdx.x; j < nv + GRAM_J; j += ITS_BLOCK) s_h[j] = j < nv ? h[j] : 0.0;
     __syncthreads();
     const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x, nth = (int64_t)gridDim.x * ITS_BLOCK;
+    const int64_t n2 = n / 2;
     double ww = 0.0;
-    for (int64_t i = tid; i < n; i += nth) {
+    for (int64_t i = tid; i < n2; i += nth) {
+        cr_v2d t; t.x = 0.0; t.y = 0.0;
+        for (int j0 = 0; j0 < nv; j0 += GRAM_J) {
+            cr_v2d v[GRAM_J];
+#pragma unroll
+            for (int u = 0; u < GRAM_J; ++u) {
+                const int j = j0 + u < nv ? j0 + u : j0;             // clamped load, coefficient 0 beyond nv
+                v[u] = reinterpret_cast<const cr_v2d *>(V + (int64_t)j * ld)[i];
+            }
+#pragma unroll
+            for (int u = 0; u < GRAM_J; ++u) { t.x = fma(s_h[j0 + u], v[u].x, t.x); t.y = fma(s_h[j0 + u], v[u].y, t.y); }
+        }
+        cr_v2d wv = reinterpret_cast<cr_v2d *>(w)[i];
+        wv.x -= t.x; wv.y -= t.y;
+        reinterpret_cast<cr_v2d *>(w)[i] = wv;
+        ww = fma(wv.y, wv.y, fma(wv.x, wv.x, ww));
+    }
+    for (int64_t i = 2 * n2 + tid; i < n; i += nth) {
         double t = 0.0;
         for (int j = 0; j < nv; ++j) t = fma(s_h[j], V[(int64_t)j * ld + i], t);
         const double wv = w[i] - t;
@@ -174,7 +207,7 @@ void launch_gram_dots(const double *w, const double *V, int64_t ld, int nv, int6
 void launch_gram_finalize(const double *part, int nv, double *h, hipStream_t s)
 { hipLaunchKernelGGL(gram_finalize_kernel, dim3(nv), dim3(ITS_BLOCK), 0, s, part, GRAM_BLOCKS, h); }
 void launch_gram_axpy(double *w, const double *V, int64_t ld, int nv, const double *h, int64_t n, double *part_ww, hipStream_t s)
-{ hipLaunchKernelGGL(gram_axpy_kernel, cr_grid(n), dim3(ITS_BLOCK), (size_t)nv * sizeof(double), s, w, V, ld, nv, h, n, part_ww); }
+{ hipLaunchKernelGGL(gram_axpy_kernel, cr_grid(n), dim3(ITS_BLOCK), (size_t)(nv + GRAM_J) * sizeof(double), s, w, V, ld, nv, h, n, part_ww); }
 void launch_gram_combine(const double *h1, const double *h2, int nv, double *hcol, hipStream_t s)
 { hipLaunchKernelGGL(gram_combine_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, h1, h2, nv, hcol); }
 
