@@ -116,6 +116,7 @@ extern "C" int its_destroy(its_handle *h)
     for (auto &e : h->prof_ev) (void)hipEventDestroy(e);
     for (auto &p : h->part) dfree(p);
     dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows); dfree(h->sweep_desc);
+    dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D);
     if (h->pinned) (void)hipHostFree(h->pinned);
     (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
     (void)hipStreamDestroy(h->stream);
@@ -263,6 +264,7 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     if (which == ITS_MAT_A) h->residual_done = false;
     if (which == ITS_MAT_L) {                     // the sweep schedule describes the old L
         dfree(h->level_rows); dfree(h->sweep_desc);
+        dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D); h->sw_w = 0;
         h->n_levels = 0; h->level_ptr.clear(); h->level_nshort.clear(); h->level_desc_first.clear(); h->level_desc_count.clear();
         h->L_rp.clear(); h->L_maxcol.clear();
     }
@@ -451,6 +453,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->watch_window_ms = value; h->watch_misses = 0;
         return ITS_OK;
     }
+    if (!strcmp(name, "sweep_ell")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_ell: 0 or 1");
+        h->sweep_ell = value;
+        return ITS_OK;
+    }
     if (!strcmp(name, "fused_residual")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "fused_residual: 0 or 1");
         h->fused_residual = value;
@@ -550,6 +557,9 @@ extern "C" int its_upload_vectors(its_handle *h, const double *D, const double *
     HIPCHK(h, hipMemcpyAsync(h->x_a, x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));   // x_old
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->setup_done = false; h->residual_done = false; h->ahead = false;
+    // the level-ordered copy of L carries the OLD diagonal: drop it (the next its_solver_setup rebuilds it; a bare
+    // its_spltsv falls back to the level-list kernel, which reads D itself)
+    dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D); h->sw_w = 0;
     return ITS_OK;
 }
 
@@ -680,6 +690,22 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
         if (dalloc(h, &h->sweep_desc, desc.size())) return ITS_EHIP;
         HIPCHK(h, hipMemcpy(h->sweep_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
     }
+    // Many scattered levels of short rows (a natural-order sweep of a stencil): level-ordered copy of L, so that a
+    // level costs two dependent memory round trips instead of four (its_kernels.hip, sweep_ell_kernel)
+    dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D); h->sw_w = 0;
+    {
+        const CsrDev &L = h->mat[ITS_MAT_L];
+        int n_list = 0;
+        for (int l = 0; l < nl; ++l) n_list += h->level_desc_count[l] == 0;
+        if (h->sweep_ell && h->D && n > 0 && nl >= 32 && n_list * 2 >= nl && L.max_row_len >= 1 && L.max_row_len <= SWEEP_ELL_W) {
+            const int W = L.max_row_len;
+            if (dalloc(h, &h->sw_col, (size_t)W * n) || dalloc(h, &h->sw_val, (size_t)W * n) || dalloc(h, &h->sw_D, (size_t)n)) return ITS_EHIP;
+            launch_sweep_ell_build(n, W, h->level_rows, L, h->D, h->sw_col, h->sw_val, h->sw_D, h->stream);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            h->sw_w = W;
+        }
+    }
     return ITS_OK;
 }
 
@@ -693,6 +719,9 @@ static int sweep(its_handle *h, double *x, const double *rhs)
         if (h->level_desc_count[l] > 0 && h->sweep_stream) {
             SpmvArgs a; a.x = x; a.y = x; a.b = rhs; a.D = h->D;   // rows of a level never read each other's x
             launch_spmv_exact_desc(L, h->sweep_desc + h->level_desc_first[l], h->level_desc_count[l], a, EPI_SWEEP, 0, h->stream);
+        } else if (h->sw_w > 0 && h->sweep_ell) {
+            launch_sweep_ell_level(L.n_rows, h->sw_w, h->level_ptr[l], h->level_ptr[l + 1], h->level_rows, h->sw_col, h->sw_val,
+                                   h->sw_D, x, rhs, h->stream);
         } else {
             launch_sweep_level(L, h->level_rows + h->level_ptr[l], cnt, h->level_nshort[l], x, rhs, h->D, h->stream);
         }

@@ -1589,6 +1589,78 @@ __global__ __launch_bounds__(ITS_BLOCK) void sweep_long_kernel(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// Level-ordered copy of L for the natural-order sweep of matrices with short rows (stencils: 766 dependency levels
+// of scattered rows at 256^3).  The level-list kernel above walks rows[k] -> row_ptr -> col/val -> x: four dependent
+// memory round trips per level, and a level is little else.  Here every position p of the level list carries its
+// row, its diagonal and its (<= W) entries of L, stored slot-major over the whole list (sw_col[s*n + p]), so a
+// level reads them with coalesced loads at once and only the gathers of x / rhs depend on them: two round trips.
+// Same entries in the same (CRS) order: bit-identical sweep.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_ell_build_kernel(
+    int n, int W, const int *__restrict__ rows, const int *__restrict__ rp, const int *__restrict__ col,
+    const double *__restrict__ val, const double *__restrict__ D, int *__restrict__ sw_col, double *__restrict__ sw_val,
+    double *__restrict__ sw_D)
+{
+    const int p = blockIdx.x * ITS_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const int row = rows[p];
+    const int j0 = rp[row], len = rp[row + 1] - j0;
+    for (int s = 0; s < W; ++s) {
+        sw_col[(size_t)s * n + p] = s < len ? col[j0 + s] : -1;
+        sw_val[(size_t)s * n + p] = s < len ? val[j0 + s] : 0.0;
+    }
+    sw_D[p] = D[row];
+}
+
+template <int W>
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_ell_kernel(
+    int n, int p0, int p1, const int *__restrict__ rows, const int *__restrict__ sw_col, const double *__restrict__ sw_val,
+    const double *__restrict__ sw_D, double *x, const double *__restrict__ rhs)
+{
+    const int p = p0 + blockIdx.x * ITS_BLOCK + threadIdx.x;
+    if (p >= p1) return;
+    const int row = rows[p];
+    int c[W]; double v[W], xv[W];
+#pragma unroll
+    for (int s = 0; s < W; ++s) { c[s] = sw_col[(size_t)s * n + p]; v[s] = sw_val[(size_t)s * n + p]; }
+    const double d = sw_D[p];
+    const double r = rhs[row];
+#pragma unroll
+    for (int s = 0; s < W; ++s) xv[s] = x[c[s] < 0 ? 0 : c[s]];
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < W; ++s) if (c[s] >= 0) acc = fma(v[s], xv[s], acc);
+    x[row] = (r - acc) / d;
+}
+
+void launch_sweep_ell_build(int n, int W, const int *rows, const CsrDev &L, const double *D, int *sw_col, double *sw_val,
+                            double *sw_D, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(sweep_ell_build_kernel, dim3((n + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, s, n, W, rows,
+                       L.row_ptr, L.col, L.val, D, sw_col, sw_val, sw_D);
+}
+
+void launch_sweep_ell_level(int n, int W, int p0, int p1, const int *rows, const int *sw_col, const double *sw_val,
+                            const double *sw_D, double *x, const double *rhs, hipStream_t s)
+{
+    if (p1 <= p0) return;
+    dim3 g((p1 - p0 + ITS_BLOCK - 1) / ITS_BLOCK), b(ITS_BLOCK);
+#define ITS_LAUNCHSW(WW) hipLaunchKernelGGL((sweep_ell_kernel<WW>), g, b, 0, s, n, p0, p1, rows, sw_col, sw_val, sw_D, x, rhs)
+    switch (W) {
+    case 1: ITS_LAUNCHSW(1); break;
+    case 2: ITS_LAUNCHSW(2); break;
+    case 3: ITS_LAUNCHSW(3); break;
+    case 4: ITS_LAUNCHSW(4); break;
+    case 5: ITS_LAUNCHSW(5); break;
+    case 6: ITS_LAUNCHSW(6); break;
+    case 7: ITS_LAUNCHSW(7); break;
+    default: ITS_LAUNCHSW(8); break;
+    }
+#undef ITS_LAUNCHSW
+}
+
 void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int n_short, double *x,
                         const double *rhs, const double *D, hipStream_t s)
 {

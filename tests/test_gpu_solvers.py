@@ -280,3 +280,28 @@ def test_odd_row_count(flag):
         del MATRICES["lap2d_15"]
     check_history(ref, args)
     assert np.max(np.abs(xs - ref["x_star"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["x_star"])))
+
+
+@pytest.mark.parametrize("name", ["lap3d_16", "lap2d_64", "cd27_6"])
+def test_natural_order_sweep_level_ordered_copy_is_bit_identical(name):
+    """Natural-order Gauss-Seidel on a stencil = many dependency levels of scattered short rows: they are swept from
+    a level-ordered copy of L (option "sweep_ell", default on; two dependent memory round trips per level instead of
+    four).  Same entries in the same order as the level-list kernel: identical histories and iterates, and equal to
+    the oracle's serial sweep."""
+    rp, col, val = MATRICES[name]()
+    n = len(rp) - 1
+    out = []
+    for ell in (1, 0):
+        args = S.Args("gauss-seidel", S.LoopParams(max_iters=40, tol=1e-13), S.Flags(), "", "none")
+        sol = S.Solver("gauss-seidel", device=0)
+        try:
+            sol.handle.set_option("sweep_ell", ell)
+            S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+            S.solve(args, sol)
+            out.append((args.normed_residuals[:args.loop_params.residual_count].copy(), sol.x_star.copy()))
+        finally:
+            sol.handle.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    orc.set_threads(1)
+    ref = orc.solve(rp, col, val, np.ones(n), np.ones(n), orc.GAUSS_SEIDEL, max_iters=40, tol=1e-13)
+    assert np.array_equal(out[0][1], ref["x_star"])

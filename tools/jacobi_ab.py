@@ -18,6 +18,7 @@ for name in sys.argv[1:] or ["jacobi"]:
             args = S.Args(name, S.LoopParams(max_iters=10**9, tol=0.0))
             sol = S.Solver(name, device=0, jacobi_mode=capi.JACOBI_REF, gs_order=order)
             sol.handle.set_option("fused_residual", fused)
+            if os.environ.get("SWEEP_ELL"): sol.handle.set_option("sweep_ell", int(os.environ["SWEEP_ELL"]))
             S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
             h = sol.handle
             for it in range(5): h.iterate(it)
