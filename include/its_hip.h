@@ -107,6 +107,8 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                  bytes per row instead of 9 nnz + 4, no LDS staging; 0 = the CRS stream kernels
  *   "spmv_ell_grid" workgroups (default 512 = 2 per CU), "spmv_ell_nt" 1 (default) = non-temporal store of the result,
  *   "spmv_ell_map" 1 (default) = row blocks dealt to the XCDs by their position inside the far band's period
+ *   "spmv_ell_wide" 1 (default) = rows of <= 32 entries with <= 255 distinct col - row (27-point stencils) run on the
+ *                  byte-index form of that image (8 W + 4 ceil(W/4) bytes per row); "spmv_ellw_grid" workgroups (768)
  *   "spmv_irr"     1 (default) = two-phase kernel when the longest row exceeds 32 entries
  *   "spmv_variant" 4 (default) | 5 | 2, "spmv_grid", "spmv_irr_grid", "spmv_irr_len", "spmv_map" 0|1:
  *                  tuning knobs kept for A/B measurements (tools/spmv_ab.py) */

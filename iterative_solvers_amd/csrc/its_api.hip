@@ -354,23 +354,27 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         pt.lap("mixed-precision image");
     }
     // sliced ELL image for short regular rows (its_ell.hip), built on the device from the arrays just uploaded
-    if (A.n_off >= 1 && A.n_off <= ELL_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELL_MAX_W && n_rows > 0 &&
-        getenv("ITS_NO_ELL") == nullptr) {
-        const int64_t n_blk = ((int64_t)n_rows + ELL_RB - 1) / ELL_RB;
-        const int64_t stored = n_blk * ELL_RB * A.max_row_len;
-        if (stored <= nnz + nnz / 4 + 8 * ELL_RB && stored < ((int64_t)1 << 40)) {
-            A.ell_w = A.max_row_len; A.ell_blocks = (int)n_blk;
-            int far = 0;
-            {
-                std::vector<int> dict(256);
-                HIPCHK(h, hipMemcpy(dict.data(), A.off_dict, 256 * sizeof(int), hipMemcpyDeviceToHost));
-                for (int i = 0; i < A.n_off; ++i) far = std::max(far, std::abs(dict[i]));
+    {
+        const bool narrow = A.n_off >= 1 && A.n_off <= ELL_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELL_MAX_W;
+        const bool wide = !narrow && A.n_off >= 1 && A.n_off <= ELLW_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELLW_MAX_W;
+        if ((narrow || wide) && n_rows > 0 && getenv("ITS_NO_ELL") == nullptr) {
+            const int64_t n_blk = ((int64_t)n_rows + ELL_RB - 1) / ELL_RB;
+            const int64_t stored = n_blk * ELL_RB * A.max_row_len;
+            if (stored <= nnz + nnz / 4 + 8 * ELL_RB && stored < ((int64_t)1 << 40)) {
+                A.ell_w = A.max_row_len; A.ell_blocks = (int)n_blk; A.ell_kind = narrow ? 1 : 2;
+                int far = 0;
+                {
+                    std::vector<int> dict(256);
+                    HIPCHK(h, hipMemcpy(dict.data(), A.off_dict, 256 * sizeof(int), hipMemcpyDeviceToHost));
+                    for (int i = 0; i < A.n_off; ++i) far = std::max(far, std::abs(dict[i]));
+                }
+                A.ell_pb = far / ELL_RB >= 8 ? far / ELL_RB : 0;
+                const size_t idx_words = narrow ? (size_t)n_blk * ELL_RB : (size_t)n_blk * ELL_RB * ((A.ell_w + 3) / 4);
+                if (dalloc(h, &A.ell_val, (size_t)stored) || dalloc(h, &A.ell_idx, idx_words)) return ITS_EHIP;
+                launch_ell_build(A, h->stream);
+                HIPCHK(h, hipGetLastError());
+                HIPCHK(h, hipStreamSynchronize(h->stream));
             }
-            A.ell_pb = far / ELL_RB >= 8 ? far / ELL_RB : 0;
-            if (dalloc(h, &A.ell_val, (size_t)stored) || dalloc(h, &A.ell_idx, (size_t)n_blk * ELL_RB)) return ITS_EHIP;
-            launch_ell_build(A, h->stream);
-            HIPCHK(h, hipGetLastError());
-            HIPCHK(h, hipStreamSynchronize(h->stream));
         }
     }
     pt.lap("ELL image");

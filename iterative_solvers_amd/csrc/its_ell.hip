@@ -128,6 +128,139 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ell_kernel(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// The same layout for WIDER rows (9..32 entries, up to 255 distinct col - row: the 27-point stencils): byte
+// dictionary indices, four to a 32-bit word, stored like the values — word q of row j of slice s at
+// idx[(s*WQ + q)*128 + j], WQ = ceil(W / 4), 0xFF = no entry.  A row is walked in batches of 8 slots (two index
+// words): the batch's 8 value loads and 16 gathers are in flight together, the chain still runs in CRS order.
+// NB = batches per row (compile time); W itself is a run-time argument, slots beyond it are not loaded.
+// --------------------------------------------------------------------------------------
+template <int NB, int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_ellw_kernel(
+    int n_rows, int n_blocks, int pb, int W, const double *__restrict__ val, const uint32_t *__restrict__ idx,
+    const int *__restrict__ dict, int nt_store, SpmvArgs a)
+{
+    __shared__ int s_dict[256];
+    __shared__ double s_red[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    s_dict[t] = t < 255 ? dict[t] : 0;
+    __syncthreads();
+    const int G = gridDim.x;
+    const int e = blockIdx.x & 7, j = blockIdx.x >> 3;
+    int b0, len, per, q_end;
+    if (pb >= 8) {
+        b0 = (int)(((int64_t)e * pb) / 8);
+        len = (int)(((int64_t)(e + 1) * pb) / 8) - b0;
+        per = pb;
+        q_end = ((n_blocks + pb - 1) / pb) * len;
+    } else {
+        b0 = (int)(((int64_t)e * n_blocks) / 8);
+        len = (int)(((int64_t)(e + 1) * n_blocks) / 8) - b0;
+        per = 0;
+        q_end = len;
+    }
+    const int WQ = (W + 3) >> 2;
+    double lane_sum = 0.0, lane_max = 0.0;
+    for (int q = j; q < q_end; q += G >> 3) {
+        const int blk = (q / len) * per + b0 + q % len;
+        if (blk >= n_blocks) continue;
+        const int sl = blk * 4 + w;
+        const int row0 = sl * ELL_S + lane * 2;
+        const bool any = row0 < n_rows, full = row0 + 1 < n_rows;
+        const uint32_t *ip = idx + (size_t)sl * WQ * ELL_S + lane * 2;
+        const double *vp = val + (size_t)sl * W * ELL_S + lane * 2;
+        // all index words of the two rows first (the gathers depend on them)
+        uint32_t iw[2 * NB][2];
+#pragma unroll
+        for (int qq = 0; qq < 2 * NB; ++qq) {
+            iw[qq][0] = 0xffffffffu; iw[qq][1] = 0xffffffffu;
+            if (qq < WQ) { const uint2 i2 = *reinterpret_cast<const uint2 *>(ip + (size_t)qq * ELL_S); iw[qq][0] = i2.x; iw[qq][1] = i2.y; }
+        }
+        double e0[2] = {0.0, 0.0}, e1[2] = {0.0, 0.0}, e2[2] = {0.0, 0.0};
+#define ELL_LD2(dst, ptr)                                                                 \
+        do {                                                                              \
+            if (full) { const ell_v2d o2 = *reinterpret_cast<const ell_v2d *>((ptr) + row0); dst[0] = o2.x; dst[1] = o2.y; } \
+            else if (any) dst[0] = (ptr)[row0];                                           \
+        } while (0)
+        if (EPI == EPI_STORE && DOT) ELL_LD2(e0, a.dotv);
+        if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) ELL_LD2(e0, a.b);
+        if (EPI == EPI_JACOBI_SHIPPED) { ELL_LD2(e0, a.D); ELL_LD2(e1, a.x); ELL_LD2(e2, a.b); }
+#undef ELL_LD2
+        double acc[2] = {0.0, 0.0}, acc2[2] = {0.0, 0.0}, diag[2] = {0.0, 0.0};
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            double v[8][2], xv[8][2];
+            int c[8][2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = 8 * bt + u;
+                v[u][0] = 0.0; v[u][1] = 0.0;
+                if (k < W) { const ell_v2d q2 = *reinterpret_cast<const ell_v2d *>(vp + (size_t)k * ELL_S); v[u][0] = q2.x; v[u][1] = q2.y; }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t by = (iw[2 * bt + (u >> 2)][r] >> (8 * (u & 3))) & 255u;
+                    c[u][r] = by == 255u ? -1 : row0 + r + s_dict[by];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) xv[u][r] = a.x[c[u][r] < 0 ? 0 : c[u][r]];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c[u][r] >= 0) chain_step<EPI>(c[u][r], row0 + r, v[u][r], xv[u][r], acc[r], acc2[r], diag[r]);
+        }
+        double outv[2] = {0.0, 0.0};
+        if (any) outv[0] = row_finish<EPI, DOT>(acc[0], acc2[0], diag[0], e0[0], e1[0], e2[0], lane_sum, lane_max);
+        if (full) outv[1] = row_finish<EPI, DOT>(acc[1], acc2[1], diag[1], e0[1], e1[1], e2[1], lane_sum, lane_max);
+        if (a.y) {
+            if (full) {
+                ell_v2d o2; o2.x = outv[0]; o2.y = outv[1];
+                if (nt_store) __builtin_nontemporal_store(o2, reinterpret_cast<ell_v2d *>(a.y + row0));
+                else *reinterpret_cast<ell_v2d *>(a.y + row0) = o2;
+            } else if (any) a.y[row0] = outv[0];
+        }
+    }
+    if (DOT || EpiKind<EPI>::norm) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) {
+            a.part_sum[blockIdx.x] = bs;
+            for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
+        }
+        if (EpiKind<EPI>::norm && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) {
+                a.part_max[blockIdx.x] = bm;
+                for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_max[z] = 0.0;
+            }
+        }
+    }
+}
+
+// wide image: values as in ell_build_kernel, byte indices packed four to a word
+__global__ __launch_bounds__(ITS_BLOCK) void ellw_build_kernel(
+    int n_rows, int n_pad, int W, const int *__restrict__ rp, const unsigned char *__restrict__ cidx,
+    const double *__restrict__ val, double *__restrict__ ell_val, uint32_t *__restrict__ ell_idx)
+{
+    const int row = blockIdx.x * ITS_BLOCK + threadIdx.x;
+    if (row >= n_pad) return;
+    const int s = row / ELL_S, jr = row % ELL_S;
+    const int WQ = (W + 3) >> 2;
+    int j0 = 0, len = 0;
+    if (row < n_rows) { j0 = rp[row]; len = rp[row + 1] - j0; }
+    for (int qq = 0; qq < WQ; ++qq) {
+        uint32_t wd = 0xffffffffu;
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * qq + u;
+            if (k < len) wd = (wd & ~(255u << (8 * u))) | ((uint32_t)cidx[j0 + k] << (8 * u));   // the offset stream's own indices
+        }
+        ell_idx[((size_t)s * WQ + qq) * ELL_S + jr] = wd;
+    }
+    for (int k = 0; k < W; ++k) ell_val[((size_t)s * W + k) * ELL_S + jr] = k < len ? val[j0 + k] : 0.0;
+}
+
 // ELL image from the device-resident CRS arrays: one lane per (padded) row
 __global__ __launch_bounds__(ITS_BLOCK) void ell_build_kernel(
     int n_rows, int n_pad, int W, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
@@ -159,6 +292,11 @@ __global__ __launch_bounds__(ITS_BLOCK) void ell_build_kernel(
 void launch_ell_build(const CsrDev &A, hipStream_t s)
 {
     const int n_pad = A.ell_blocks * ELL_RB;
+    if (A.ell_kind == 2) {
+        hipLaunchKernelGGL(ellw_build_kernel, dim3((n_pad + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, s, A.n_rows, n_pad,
+                           A.ell_w, A.row_ptr, A.cidx, A.val, A.ell_val, A.ell_idx);
+        return;
+    }
     hipLaunchKernelGGL(ell_build_kernel, dim3((n_pad + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, s, A.n_rows, n_pad,
                        A.ell_w, A.row_ptr, A.col, A.val, A.off_dict, A.n_off, A.ell_val, A.ell_idx);
 }
@@ -167,6 +305,8 @@ static int ell_env(const char *name, int dflt) { const char *e = getenv(name); r
 static int g_ell_on = ell_env("ITS_SPMV_ELL", 1);
 static int g_ell_grid = ell_env("ITS_SPMV_ELL_GRID", 512);
 static int g_ell_nt = ell_env("ITS_SPMV_ELL_NT", 1);
+static int g_ellw_grid = ell_env("ITS_SPMV_ELLW_GRID", 768);      // 3 workgroups per CU: the byte-index kernel holds 3 waves per SIMD
+static int g_ell_wide = ell_env("ITS_SPMV_ELL_WIDE", 1);      // 0 = rows of 9..32 entries stay on the CRS stream kernels
 static int g_ell_map = ell_env("ITS_SPMV_ELL_MAP", 1);       // 0 = contiguous eighth per XCD even for far-banded matrices
 
 int ell_tune(const char *name, int value)
@@ -174,6 +314,8 @@ int ell_tune(const char *name, int value)
     if (!strcmp(name, "spmv_ell")) { if (value < 0 || value > 1) return -1; g_ell_on = value; return 0; }
     if (!strcmp(name, "spmv_ell_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_ell_grid = value; return 0; }
     if (!strcmp(name, "spmv_ell_nt")) { if (value < 0 || value > 1) return -1; g_ell_nt = value; return 0; }
+    if (!strcmp(name, "spmv_ellw_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_ellw_grid = value; return 0; }
+    if (!strcmp(name, "spmv_ell_wide")) { if (value < 0 || value > 1) return -1; g_ell_wide = value; return 0; }
     if (!strcmp(name, "spmv_ell_map")) { if (value < 0 || value > 1) return -1; g_ell_map = value; return 0; }
     return -2;
 }
@@ -183,6 +325,7 @@ static inline bool al16p(const void *p) { return (reinterpret_cast<uintptr_t>(p)
 bool spmv_ell_eligible(const CsrDev &A, const SpmvArgs &a, int epi)
 {
     if (!g_ell_on || !A.ell_val || epi == EPI_SWEEP || spmv_valdict_selected(A)) return false;
+    if (A.ell_kind == 2 && !g_ell_wide) return false;
     // two rows per lane move as 16-byte accesses: every per-row vector must be 16-byte aligned (solver vectors are)
     return al16p(a.y) && al16p(a.b) && al16p(a.D) && al16p(a.dotv) && (epi != EPI_JACOBI_SHIPPED || al16p(a.x));
 }
@@ -206,10 +349,40 @@ static void launch_ell_w(const CsrDev &A, const SpmvArgs &a, int epi, int grid, 
 #undef ITS_LAUNCHE
 }
 
+template <int NB>
+static void launch_ellw_nb(const CsrDev &A, const SpmvArgs &a, int epi, int grid, int pb, int nt, hipStream_t s)
+{
+    dim3 g(grid), b(ITS_BLOCK);
+#define ITS_LAUNCHW(E, D) \
+    hipLaunchKernelGGL((spmv_ellw_kernel<NB, E, D>), g, b, 0, s, A.n_rows, A.ell_blocks, pb, A.ell_w, A.ell_val, A.ell_idx, A.off_dict, nt, a)
+    switch (epi) {
+    case EPI_STORE: if (a.dotv) ITS_LAUNCHW(EPI_STORE, true); else ITS_LAUNCHW(EPI_STORE, false); break;
+    case EPI_RESIDUAL: ITS_LAUNCHW(EPI_RESIDUAL, false); break;
+    case EPI_JACOBI_SHIPPED: ITS_LAUNCHW(EPI_JACOBI_SHIPPED, false); break;
+    case EPI_JACOBI_REF: ITS_LAUNCHW(EPI_JACOBI_REF, false); break;
+    case EPI_GS_RHS: ITS_LAUNCHW(EPI_GS_RHS, false); break;
+    case EPI_JACOBI_FUSED: ITS_LAUNCHW(EPI_JACOBI_FUSED, false); break;
+    case EPI_GS_FUSED: ITS_LAUNCHW(EPI_GS_FUSED, false); break;
+    default: break;
+    }
+#undef ITS_LAUNCHW
+}
+
 void launch_spmv_ell(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
 {
     SpmvArgs a = a_in;
     a.part_accum = 0;
+    if (A.ell_kind == 2) {
+        int grid = g_ellw_grid;
+        const int need = ((A.ell_blocks + 7) / 8) * 8;
+        if (grid > need) grid = need < 8 ? 8 : need;
+        const int pb = g_ell_map ? A.ell_pb : 0;
+        const int nb = (A.ell_w + 7) / 8;
+        if (nb <= 2) launch_ellw_nb<2>(A, a, epi, grid, pb, g_ell_nt, s);
+        else if (nb == 3) launch_ellw_nb<3>(A, a, epi, grid, pb, g_ell_nt, s);
+        else launch_ellw_nb<4>(A, a, epi, grid, pb, g_ell_nt, s);
+        return;
+    }
     int grid = g_ell_grid;
     // small matrices: no more workgroups than row blocks (multiple of 8: the XCD map)
     const int need = ((A.ell_blocks + 7) / 8) * 8;

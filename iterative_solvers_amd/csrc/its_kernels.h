@@ -28,6 +28,8 @@ constexpr int ELL_S = 128;
 constexpr int ELL_RB = 4 * ELL_S;
 constexpr int ELL_MAX_W = 8;              // longest row an ELL image is built for (8 nibbles in the index word)
 constexpr int ELL_MAX_OFF = 15;           // dictionary entries a nibble can name (0xF = no entry)
+constexpr int ELLW_MAX_W = 32;            // longest row of the byte-index form
+constexpr int ELLW_MAX_OFF = 255;         // its dictionary (0xFF = no entry)
 
 enum SpmvEpilogue {
     EPI_STORE = 0,        // y = A x                                  (kernels.hpp:380-409)
@@ -67,6 +69,8 @@ struct CsrDev {
     double *ell_val = nullptr;
     uint32_t *ell_idx = nullptr;
     int ell_w = 0, ell_blocks = 0, ell_pb = 0;
+    int ell_kind = 0;                         // 1: nibble index word per row (rows <= 8, <= 15 offsets); 2: byte indices, four to a
+                                              // word, slot-major like the values (rows <= 32, <= 255 offsets)
     // mixed-precision image (ITS_FMT_MIXED): the entries at or above the threshold as an fp64 CRS, the rest as an
     // fp32 CRS, both in the row order of the original
     int *mix_rp_d = nullptr, *mix_col_d = nullptr, *mix_rp_s = nullptr, *mix_col_s = nullptr;

@@ -3,7 +3,7 @@
 The ELL image stores the CRS entries of every row in CRS order and the kernel runs the reference's in-order fused
 chain per row (kernels.hpp:380-409), so every epilogue must be BIT-identical to the oracle and to the CRS stream
 kernels it replaces ("spmv_ell" 0).  Covers: row counts around the slice / row-block sizes (128 / 512 rows), rows
-of 0..8 entries, the period work map (far band >= 8 row blocks) on and off, all epilogues the solver trips launch,
+of 0..8 entries (nibble indices) and of 9..32 entries or up to 255 offsets (byte indices), the period work map (far band >= 8 row blocks) on and off, all epilogues the solver trips launch,
 unaligned caller vectors (fall back to the CRS kernels) and matrices that are not eligible."""
 import numpy as np
 import pytest
@@ -42,15 +42,42 @@ CASES = {
     "lap2d_64": lambda: matgen.laplace2d_5pt(64),
     "lap3d_20": lambda: matgen.laplace3d_7pt(20),
     "lap3d_64": lambda: matgen.laplace3d_7pt(64),                               # period map: 4096 // 512 = 8 blocks
+    # the byte-index form (spmv_ellw_kernel): rows of 9..32 entries, <= 255 distinct offsets
+    "wide_w9": lambda: banded(3000, [-40, -9, -3, -1, 0, 1, 3, 9, 40], 21, drop=0.02),
+    "wide_w17": lambda: banded(2049, list(range(-8, 9)), 22, drop=0.05),
+    "wide_w32": lambda: banded(4097, list(range(-16, 16)), 23, drop=0.03),
+    "wide_w33": lambda: banded(4097, list(range(-16, 17)), 24, drop=0.0),       # one entry too long: CRS kernels
+    "wide_w8_20off": lambda: _shifting(6000, 25),                               # rows of 8, 20 offsets: too many for nibbles
+    "cd27_20": lambda: matgen.convdiff3d_27pt(20),
+    "cd27_48": lambda: matgen.convdiff3d_27pt(48),                              # period map: 2353 // 512 ... below 8: chunk map
+    "cd27_72": lambda: matgen.convdiff3d_27pt(72),                              # far band 5257 -> 10 row blocks: period map
 }
 
 
-def _eligible(rp):
-    """the upload's padding rule: stored slots (row blocks of 512 rows x longest row) within 25 % of nnz"""
+def _shifting(n, seed):
+    """8 entries per row whose offsets depend on row % 5: more than 15 distinct offsets over the matrix"""
+    rng = np.random.default_rng(seed)
+    rp = [0]; col = []; val = []
+    for i in range(n):
+        for o in sorted({-60 - i % 5, -11 + i % 5, -2, 0, 1, 3 + i % 5, 20 - i % 5, 64 + i % 5}):
+            if 0 <= i + o < n:
+                col.append(i + o); val.append(rng.uniform(-1, 1))
+        rp.append(len(col))
+    return np.array(rp, np.int32), np.array(col, np.int32), np.array(val)
+
+
+def _eligible(rp, col):
+    """the upload's rule: "spmv_ell_kernel" for rows <= 8 with <= 15 distinct offsets, "spmv_ellw_kernel" for rows <= 32
+    with <= 255, both only when the stored slots (row blocks of 512 rows x longest row) are within 25 % of nnz"""
     n = len(rp) - 1
     w = int(np.diff(rp).max()) if n else 0
     nnz = int(rp[-1])
-    return 1 <= w <= 8 and -(-n // 512) * 512 * w <= nnz + nnz // 4 + 8 * 512
+    if not (1 <= w <= 32 and -(-n // 512) * 512 * w <= nnz + nnz // 4 + 8 * 512):
+        return None
+    n_off = len(np.unique(col - np.repeat(np.arange(n), np.diff(rp))))
+    if w <= 8 and n_off <= 15:
+        return "spmv_ell_kernel"
+    return "spmv_ellw_kernel" if n_off <= 255 else None
 
 
 def _kernel(h, with_dot=False):
@@ -68,13 +95,15 @@ def test_ell_store_bit_exact(gpu_handle, name):
     try:
         for ell, mp in ((1, 1), (1, 0), (0, 1)):
             h.set_option("spmv_ell", ell); h.set_option("spmv_ell_map", mp)
-            assert (_kernel(h) == "spmv_ell_kernel") == bool(ell and _eligible(rp)), name
+            want = _eligible(rp, col) if ell else None
+            assert (_kernel(h) if want else want) == want and (want or not _kernel(h).startswith("spmv_ell")), (name, _kernel(h))
             assert np.array_equal(h.spmv_host(x, n, capi.MAT_A, capi.FMT_CSR_EXACT), ref), (name, ell, mp)
     finally:
         h.set_option("spmv_ell", 1); h.set_option("spmv_ell_map", 1)
 
 
-@pytest.mark.parametrize("name", ["n513", "n5001_w8", "far_band", "lap3d_20", "lap3d_64"])
+@pytest.mark.parametrize("name", ["n513", "n5001_w8", "far_band", "lap3d_20", "lap3d_64", "wide_w9", "wide_w17", "wide_w32",
+                                  "wide_w8_20off", "cd27_20", "cd27_72"])
 def test_ell_every_epilogue_matches_the_crs_kernels(gpu_handle, name):
     """its_spmv_timed modes 0..7 launch the epilogues of the solver trips (plain, CG form, residual stored / norm
     only, Jacobi sweep, GS right-hand side and the two fused forms) with b := x; the stored vectors must agree bit
@@ -134,8 +163,17 @@ def test_ell_not_built_for_ineligible_matrices(gpu_handle):
     for mk in (lambda: matgen.convdiff3d_27pt(6), lambda: matgen.powerlaw(300)):
         rp, col, val = mk()
         h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
-        assert _kernel(h) != "spmv_ell_kernel"
+        assert not _kernel(h).startswith("spmv_ell")
     rp, col, val = matgen.laplace3d_7pt(8)
     h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
     name, streamed = h.spmv_kernel_info(capi.MAT_A, True)
     assert name == "spmv_ell_kernel" and streamed == 512 * (8 * 7 + 4) + 16 * 512
+    rp, col, val = matgen.convdiff3d_27pt(16)
+    h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+    name, streamed = h.spmv_kernel_info(capi.MAT_A, True)
+    assert name == "spmv_ellw_kernel" and streamed == 4096 * (8 * 27 + 4 * 7) + 16 * 4096
+    h.set_option("spmv_ell_wide", 0)
+    try:
+        assert not _kernel(h).startswith("spmv_ell")
+    finally:
+        h.set_option("spmv_ell_wide", 1)
