@@ -114,6 +114,50 @@ __global__ __launch_bounds__(NT) void panel_kernel(const int *__restrict__ tile_
     }
 }
 
+// ---- design B: no staging, no barriers.  A wave owns RW rows (running sums in LDS); its entries come as GROUPS of 64 whose
+// rows are pairwise distinct, in an order that keeps every row's entries in CRS order.  key = row_in_wave << 22 | column
+// relative to the group's base column.
+constexpr int BSHIFT = 21;            // 11 bits of row (RW + 1 slots with the dummy row of the padding), 21 of column
+constexpr uint32_t BMASK = (1u << BSHIFT) - 1;
+template <int RW, int G, int WPB>
+__global__ __launch_bounds__(WPB * 64) void wave_panel_kernel(int n_wstripes, const int *__restrict__ wptr, const int *__restrict__ gbase,
+                                                              const uint32_t *__restrict__ key, const double *__restrict__ val,
+                                                              const double *__restrict__ x, double *__restrict__ y, int n_rows,
+                                                              const unsigned char *__restrict__ is_long)
+{
+    __shared__ double s_acc[WPB * (RW + 1)];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ws = blockIdx.x * WPB + w;
+    if (ws >= n_wstripes) return;
+    double *acc = s_acc + w * (RW + 1);
+    for (int i = lane; i <= RW; i += 64) acc[i] = 0.0;
+    const int g0 = wptr[ws], g1 = wptr[ws + 1];          // multiple of G groups
+    uint32_t k[G], kn[G]; double v[G], vn[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) { kn[u] = 0; vn[u] = 0.0; }
+    if (g0 < g1) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) { kn[u] = __builtin_nontemporal_load(key + (int64_t)(g0 + u) * 64 + lane); vn[u] = __builtin_nontemporal_load(val + (int64_t)(g0 + u) * 64 + lane); }
+    }
+    for (int g = g0; g < g1; g += G) {
+        double xx[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) { k[u] = kn[u]; v[u] = vn[u]; }
+#pragma unroll
+        for (int u = 0; u < G; ++u) xx[u] = x[(int64_t)gbase[g + u] + (k[u] & BMASK)];
+        if (g + G < g1) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) { kn[u] = __builtin_nontemporal_load(key + (int64_t)(g + G + u) * 64 + lane); vn[u] = __builtin_nontemporal_load(val + (int64_t)(g + G + u) * 64 + lane); }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) { const int r = k[u] >> BSHIFT; acc[r] = fma(v[u], xx[u], acc[r]); }
+    }
+    for (int i = lane; i < RW; i += 64) {
+        const int row = ws * RW + i;
+        if (row < n_rows && !is_long[row]) y[row] = acc[i];
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 10000000;
@@ -224,6 +268,90 @@ int main(int argc, char **argv)
         fflush(stdout);
         CK(hipFree(dkey)); CK(hipFree(dval)); CK(hipFree(ddesc)); CK(hipFree(dtp));
     };
+
+    const int LCUT = getenv("LCUT") ? atoi(getenv("LCUT")) : 64;
+    auto runB = [&](auto kern, int RW, int G, int WPB, const char *tag) {
+        if (only >= 0 && run_no++ != only) return;
+        const int P = (n + (1 << log2pw) - 1) >> log2pw;
+        const int nws = (n + RW - 1) / RW;
+        std::vector<unsigned char> is_long(n);
+        int64_t nnz_short = 0;
+        for (int i = 0; i < n; ++i) { is_long[i] = rp[i + 1] - rp[i] > LCUT; if (!is_long[i]) nnz_short += rp[i + 1] - rp[i]; }
+        std::vector<std::vector<uint32_t>> wkey(nws); std::vector<std::vector<double>> wval(nws); std::vector<std::vector<int>> wbase(nws);
+#pragma omp parallel
+        {
+            std::vector<int64_t> cur(RW);                // next entry of each row
+            std::vector<int> ingroup(RW);                // group index a row was last placed in
+#pragma omp for schedule(dynamic, 16)
+            for (int ws = 0; ws < nws; ++ws) {
+                const int r0 = ws * RW, r1 = std::min(n, r0 + RW);
+                for (int r = r0; r < r1; ++r) { cur[r - r0] = rp[r]; ingroup[r - r0] = -1; }
+                auto &K = wkey[ws]; auto &V = wval[ws]; auto &B = wbase[ws];
+                int fill = 64;                           // slots used in the open group (64 = none open)
+                int gi = -1; int base = 0;
+                auto open = [&](int b) { while (fill < 64) { K.push_back((uint32_t)RW << BSHIFT); V.push_back(0.0); ++fill; } ++gi; base = b; B.push_back(b); fill = 0; };
+                for (int p = 0; p < P; ++p) {
+                    const int pend = std::min<int64_t>(n, ((int64_t)p + 1) << log2pw);
+                    bool more = true;
+                    while (more) {                       // rounds: the next entry of every row that still has one in this panel
+                        more = false;
+                        for (int r = r0; r < r1; ++r) {
+                            if (is_long[r]) continue;
+                            int64_t &c = cur[r - r0];
+                            if (c < rp[r + 1] && col[c] < pend) {
+                                if (fill == 64 || ingroup[r - r0] == gi || (int64_t)col[c] - base > (int64_t)BMASK) open(p << log2pw);
+                                K.push_back(((uint32_t)(r - r0) << BSHIFT) | (uint32_t)(col[c] - base)); V.push_back(val[c]); ++fill;
+                                ingroup[r - r0] = gi;
+                                ++c;
+                                if (c < rp[r + 1] && col[c] < pend) more = true;
+                            }
+                        }
+                    }
+                }
+                while (fill < 64) { K.push_back((uint32_t)RW << BSHIFT); V.push_back(0.0); ++fill; }
+                while (B.size() % G) { B.push_back(0); for (int q = 0; q < 64; ++q) { K.push_back((uint32_t)RW << BSHIFT); V.push_back(0.0); } }
+            }
+        }
+        std::vector<int> wptr(nws + 1, 0);
+        for (int ws = 0; ws < nws; ++ws) wptr[ws + 1] = wptr[ws] + (int)wbase[ws].size();
+        const int64_t ng = wptr[nws];
+        std::vector<uint32_t> key(ng * 64); std::vector<double> pv(ng * 64); std::vector<int> gb(ng);
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int ws = 0; ws < nws; ++ws) {
+            std::copy(wkey[ws].begin(), wkey[ws].end(), key.begin() + (int64_t)wptr[ws] * 64);
+            std::copy(wval[ws].begin(), wval[ws].end(), pv.begin() + (int64_t)wptr[ws] * 64);
+            std::copy(wbase[ws].begin(), wbase[ws].end(), gb.begin() + wptr[ws]);
+        }
+        int *dgb; unsigned char *dlong;
+        CK(hipMalloc(&dkey, ng * 64 * 4)); CK(hipMalloc(&dval, ng * 64 * 8)); CK(hipMalloc(&dgb, ng * 4)); CK(hipMalloc(&dtp, wptr.size() * 4)); CK(hipMalloc(&dlong, n));
+        CK(hipMemcpy(dkey, key.data(), ng * 64 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dval, pv.data(), ng * 64 * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dgb, gb.data(), ng * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dtp, wptr.data(), wptr.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dlong, is_long.data(), n, hipMemcpyHostToDevice));
+        CK(hipMemset(dy, 0, (size_t)n * 8));
+        const int grid = (nws + WPB - 1) / WPB;
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), 0, 0, nws, dtp, dgb, dkey, dval, dx, dy, n, dlong);
+        CK(hipGetLastError());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), 0, 0, nws, dtp, dgb, dkey, dval, dx, dy, n, dlong);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+        std::vector<double> yh(n);
+        CK(hipMemcpy(yh.data(), dy, (size_t)n * 8, hipMemcpyDeviceToHost));
+        int64_t bad = 0;
+        for (int i = 0; i < n; ++i) bad += !is_long[i] && memcmp(&yh[i], &yref[i], 8) != 0;
+        printf("B %-26s LCUT %d: %lld of %lld entries, groups %lld fill %.3f  %.4f ms  %.1f G entries/s  mismatching rows %lld\n", tag, LCUT,
+               (long long)nnz_short, (long long)nnz, (long long)ng, nnz_short / (ng * 64.0), ms, nnz_short / ms / 1e6, (long long)bad);
+        fflush(stdout);
+        CK(hipFree(dkey)); CK(hipFree(dval)); CK(hipFree(dgb)); CK(hipFree(dtp)); CK(hipFree(dlong));
+    };
+    if (getenv("DESIGN_B")) {
+        runB(wave_panel_kernel<1024, 4, 4>, 1024, 4, 4, "RW 1024 G 4 WPB 4");
+        runB(wave_panel_kernel<1024, 8, 4>, 1024, 8, 4, "RW 1024 G 8 WPB 4");
+        runB(wave_panel_kernel<1024, 2, 4>, 1024, 2, 4, "RW 1024 G 2 WPB 4");
+        runB(wave_panel_kernel<1024, 4, 1>, 1024, 4, 1, "RW 1024 G 4 WPB 1");
+        runB(wave_panel_kernel<512, 4, 4>, 512, 4, 4, "RW 512 G 4 WPB 4");
+        return 0;
+    }
     if (TRsel == 4096) {
         run(panel_kernel<4096, 512, 256>, 4096, 512, 256, "TR 4096 CH 512 NT 256");
         run(panel_kernel<4096, 1024, 256>, 4096, 1024, 256, "TR 4096 CH 1024 NT 256");
