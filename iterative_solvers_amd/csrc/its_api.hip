@@ -1314,15 +1314,18 @@ extern "C" int its_spmv(its_handle *h, int which, const double *x, double *y, in
         return ITS_OK;
     }
     double *dx = nullptr, *dy = nullptr;
-    if (dalloc(h, &dx, A.n_cols) || dalloc(h, &dy, A.n_rows)) return ITS_EHIP;
-    HIPCHK(h, hipMemcpyAsync(dx, x, (size_t)A.n_cols * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    SpmvArgs a; a.x = dx; a.y = dy;
-    int rc = spmv_dispatch(h, A, a, EPI_STORE, format);
-    if (rc == ITS_OK) {
-        hipError_t e = hipMemcpyAsync(y, dy, (size_t)A.n_rows * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = ITS_EHIP; }
+    if (dalloc(h, &dx, A.n_cols) || dalloc(h, &dy, A.n_rows)) { dfree(dx); dfree(dy); return ITS_EHIP; }
+    int rc = ITS_OK;
+    hipError_t e = hipMemcpyAsync(dx, x, (size_t)A.n_cols * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        SpmvArgs a; a.x = dx; a.y = dy;
+        rc = spmv_dispatch(h, A, a, EPI_STORE, format);
+        if (rc == ITS_OK) e = hipMemcpyAsync(y, dy, (size_t)A.n_rows * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     }
+    // the staging vectors are released on every path, and only once nothing queued on the stream still reads them
+    const hipError_t es = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = es;
+    if (rc == ITS_OK && e != hipSuccess) { h->err = hipGetErrorString(e); rc = ITS_EHIP; }
     dfree(dx); dfree(dy);
     return rc;
 }
