@@ -275,7 +275,14 @@ def main():
     # rehearsal of the N > 1 path on a one-GPU box: ITS_BENCH_TRANSPORT=host puts every rank on GPU 0 and
     # moves halo entries / scalars through the TCP rendezvous instead of RCCL (never a reported number)
     host_transport = os.environ.get("ITS_BENCH_TRANSPORT", "rccl") == "host"
-    sol = S.Solver("conjugate-gradient", device=0 if host_transport else local_rank, spmv_format=fmt)
+    # rank -> GPU: the local rank, or (a launcher that masks the devices per rank) whatever single device is visible
+    n_dev = capi.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: no HIP device visible to rank %d" % rank)
+    if world > 1 and not host_transport and 1 < n_dev < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit("bench.py: %d ranks on this node but only %d GPUs visible: RCCL needs one GPU per rank" %
+                         (int(os.environ.get("LOCAL_WORLD_SIZE", world)), n_dev))
+    sol = S.Solver("conjugate-gradient", device=0 if host_transport else local_rank % n_dev, spmv_format=fmt)
     h = sol.handle
     # ITS_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL communicators, split SpMV, all-reduced
     # scalars) even at world = 1, to see what that path costs per trip without a second GPU

@@ -52,6 +52,9 @@ enum { ITS_GS_LEVEL = 0, ITS_GS_MULTICOLOR = 1 };
 /* ---- library / handle --------------------------------------------------------------- */
 /* start of run_solver (main.cpp:331).  device < 0 keeps the current device. */
 int its_create(its_handle **h, int device);
+/* HIP devices visible to this process (0 when there is none or the runtime cannot start): what a one-process-per-GPU
+ * launcher maps its local rank onto (no counterpart in the reference: single process, main.cpp:94) */
+int its_device_count(void);
 /* end of run_solver (main.cpp:492-519) */
 int its_destroy(its_handle *h);
 const char *its_last_error(const its_handle *h);

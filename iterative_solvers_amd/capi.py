@@ -29,6 +29,7 @@ _c_dbl_p = C.POINTER(C.c_double)
 # name -> (restype, argtypes); every symbol include/its_hip.h declares
 SIGNATURES = {
     "its_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "its_device_count": (C.c_int, []),
     "its_destroy": (C.c_int, [C.c_void_p]),
     "its_last_error": (C.c_char_p, [C.c_void_p]),
     "its_version": (C.c_char_p, []),
@@ -149,6 +150,11 @@ def permute_crs(row_ptr, col, val, perm_new2old):
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    """HIP devices visible to this process (0: none)."""
+    return int(lib().its_device_count())
 
 
 class Handle:

@@ -72,6 +72,12 @@ static int size_pinned(its_handle *h, int m)
     return ITS_OK;
 }
 
+extern "C" int its_device_count(void)
+{
+    int ndev = 0;
+    return hipGetDeviceCount(&ndev) == hipSuccess ? ndev : 0;
+}
+
 extern "C" int its_create(its_handle **out, int device)
 {
     if (!out) return ITS_EINVAL;
