@@ -253,6 +253,10 @@ def main():
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a.gpus, sys.argv[1:])               # never returns
 
+    # multi-process GPU work on this host driver needs dmabuf IPC (RCCL fails with `hipIpcGetMemHandle: invalid
+    # argument` otherwise); set before the HIP runtime is loaded, whatever the launcher exported
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     # NOTE: this process never imports torch — PyTorch's wheel bundles a second ROCm runtime
     # (7.0) that must not share an address space with the /opt/rocm runtime libits_hip.so uses
     # (iterative_solvers_amd/rendezvous.py explains).  The launcher may still be
