@@ -50,7 +50,7 @@ def kernel_sources_hash():
     import hashlib
     hsh = hashlib.sha256()
     # the files that hold device code (host-side API changes do not invalidate a counter profile)
-    names = ("its_kernels.hip", "its_ell.hip", "its_epilogue.h", "its_device.h", "its_kernels.h")
+    names = ("its_kernels.hip", "its_ell.hip", "its_panel.hip", "its_epilogue.h", "its_device.h", "its_kernels.h")
     for f in sorted(os.path.join(ROOT, "iterative_solvers_amd", "csrc", nm) for nm in names):
         hsh.update(os.path.basename(f).encode()); hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]

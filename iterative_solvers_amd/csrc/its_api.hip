@@ -35,11 +35,14 @@ struct PhaseTimer {
     }
 };
 
+int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp);    // its_panel.hip
+
 static void free_csr(CsrDev &A)
 {
     dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc); dfree(A.blk_desc_big);
     dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict); dfree(A.vidx); dfree(A.val_dict);
     dfree(A.ell_val); dfree(A.ell_idx);
+    dfree(A.pan_key); dfree(A.pan_val); dfree(A.pan_desc); dfree(A.pan_tile_ptr); dfree(A.pan_long); dfree(A.pan_long_rows);
     dfree(A.mix_rp_d); dfree(A.mix_col_d); dfree(A.mix_val_d); dfree(A.mix_rp_s); dfree(A.mix_col_s); dfree(A.mix_val_s);
     A = CsrDev();
 }
@@ -384,6 +387,12 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         }
     }
     pt.lap("ELL image");
+    if (which == ITS_MAT_A) {
+        // column-panel blocked image for large irregular matrices (its_panel.hip)
+        int rcp = build_panel_image(h, A, row_ptr);
+        if (rcp) return rcp;
+        pt.lap("panel image");
+    }
     if (which == ITS_MAT_L) {
         h->L_rp.assign(row_ptr, row_ptr + n_rows + 1);
         h->L_maxcol.assign((size_t)std::max(n_rows, 1), -1);
@@ -477,6 +486,7 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
     {
         int rc = spmv_tune(name, value);            // process-wide launch tunables of the exact SpMV
         if (rc == -2) rc = ell_tune(name, value);
+        if (rc == -2) rc = panel_tune(name, value);
         if (rc == 0) return ITS_OK;
         if (rc == -1) FAIL(h, ITS_EINVAL, std::string("bad value for option ") + name);
     }

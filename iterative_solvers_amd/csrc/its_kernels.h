@@ -17,6 +17,12 @@ constexpr int SPMV_NNZ_MAX = 1536;        // (1536+8)*(8+4) B + row ptrs ≈ 19.
 // hold 2048 entries per trip, and with 256 full rows per block (7-pt: 1792 entries) it runs 3 % faster; the
 // four-per-CU kernel needs the smaller LDS footprint of SPMV_NNZ_MAX
 constexpr int SPMV_NNZ_BIG = 2040;
+// column-panel blocked image of large irregular matrices (its_panel.hip)
+constexpr int PAN_TR = 4096;              // rows per tile: their running sums live in LDS (32 KB)
+constexpr int PAN_CH = 256;               // entries per chunk (one per lane); a chunk never spans two panels
+constexpr int PAN_LCUT = 128;             // rows longer than this stay on the irregular-row kernel
+constexpr int PAN_COLBITS = 19;           // key = row in tile << 19 | column in panel
+constexpr uint32_t PAN_COLMASK = (1u << PAN_COLBITS) - 1u;
 constexpr int IRR_ROW_LEN = 32;           // longest row above which the exact SpMV splits gather and arithmetic
 // col/val are allocated with this many zero elements after nnz: the stream kernel's prefetch
 // loads are unconditional (2 slices x 1024 entries past an aligned block start)
@@ -85,6 +91,13 @@ struct CsrDev {
     // vector-CSR plan
     int lanes_per_row = 0;
     int max_row_len = 0;                      // longest row: > IRR_ROW_LEN selects the irregular-row exact kernel
+    // panel image (its_panel.hip; only for large irregular A): entries of the rows of <= PAN_LCUT entries sorted by
+    // (tile, panel, row, position in row) as (key, value); chunk descriptors {first entry, entries | panel << 9} of
+    // tile t at pan_desc[pan_tile_ptr[t] .. pan_tile_ptr[t+1]); the longer rows, longest first, in pan_long_rows
+    uint32_t *pan_key = nullptr; double *pan_val = nullptr; int2 *pan_desc = nullptr; int *pan_tile_ptr = nullptr;
+    unsigned char *pan_long = nullptr; int *pan_long_rows = nullptr;
+    int pan_tiles = 0, pan_n_long = 0, pan_log2pw = 0, pan_chunks = 0;
+    int64_t pan_nnz = 0;
     int64_t n_upper = 0;                      // entries with col > row (what a matching crs_U must hold)
     int64_t upper_col_sum = 0;                // their column sum and a hash of their values: crs_U is compared on all three
     uint64_t upper_val_xor = 0;
@@ -125,6 +138,9 @@ const char *spmv_exact_kernel_name(const CsrDev &A, const SpmvArgs &a, int epilo
 // sliced-ELL form of the exact SpMV (its_ell.hip): whole-matrix launches of eligible matrices
 bool spmv_valdict_selected(const CsrDev &A);            // option "spmv_valdict" applies to this matrix
 bool spmv_ell_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);
+bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);     // its_panel.hip
+void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
+int panel_tune(const char *name, int value);             // "spmv_panel", "spmv_panel_min_cols", "spmv_panel_log2pw", "spmv_panel_grid"
 void launch_spmv_ell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 void launch_ell_build(const CsrDev &A, hipStream_t s);   // fills ell_val / ell_idx from the device CRS arrays
 int ell_tune(const char *name, int value);               // "spmv_ell", "spmv_ell_grid", "spmv_ell_nt", "spmv_ell_map"

@@ -926,6 +926,11 @@ const char *spmv_exact_kernel_name(const CsrDev &A, const SpmvArgs &a, int epi, 
         if (streamed) *streamed = (int64_t)A.ell_blocks * ELL_RB * (8 * A.ell_w + 4) + 16 * n;
         return "spmv_ell_kernel";
     }
+    if (spmv_panel_eligible(A, a, epi)) {
+        // image entries at 12 bytes, chunk descriptors, the long rows in CRS form, the long-row flags, x and y once
+        if (streamed) *streamed = 12 * A.pan_nnz + 8 * (int64_t)A.pan_chunks + 12 * (nnz - A.pan_nnz) + 12 * (int64_t)A.pan_n_long + n + 16 * n;
+        return "spmv_panel_kernel";
+    }
     if (A.max_row_len > g_spmv_irr_len && g_spmv_irr) { if (streamed) *streamed = 12 * nnz + 4 * (n + 1) + 16 * n; return "spmv_irr_kernel"; }
     if (A.max_row_len <= 8 && (g_spmv_variant == 5 || (g_spmv_variant == 4 && cmp == 2))) return "spmv_stream5_kernel";
     if (g_spmv_variant == 4 && A.max_row_len <= 8 && epi == EPI_STORE && a.dotv) return "spmv_stream4_kernel";
@@ -935,6 +940,7 @@ const char *spmv_exact_kernel_name(const CsrDev &A, const SpmvArgs &a, int epi, 
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
 {
     if (spmv_ell_eligible(A, a_in, epi)) { launch_spmv_ell(A, a_in, epi, s); return; }
+    if (spmv_panel_eligible(A, a_in, epi)) { launch_spmv_panel(A, a_in, epi, s); return; }
     if (spmv_exact_takes_big_plan(A, a_in, epi)) launch_spmv_exact_desc(A, A.blk_desc_big, A.n_blocks_big, a_in, epi, 0, s);
     else launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s);
 }

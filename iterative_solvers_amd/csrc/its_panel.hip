@@ -1,0 +1,394 @@
+// its_panel.hip — the exact SpMV for large IRREGULAR matrices whose x does not fit an XCD's L2 (the 10 M-row power-law
+// matrix: x = 80 MB), column-panel blocked so that most gathers hit L2 instead of the Infinity Cache.
+//
+// Why.  With one gather per nonzero into an 80 MB vector every exact, vector and SELL kernel sits on the chip's rate
+// for isolated 8-byte gathers from the Infinity Cache (56.5 G/s, tools/gatherlab.hip: 1.49 ms for 84 M entries); an
+// L2-resident table serves the same loop at 200 G/s.
+// How.  The bit-exactness contract (spmv_crs_cpu, kernels.hpp:380-409) fixes the ORDER of a row's multiply-adds, not
+// where its entries live.  If every row's columns ascend, walking x in column PANELS keeps each row's chain order: the
+// entries of a row that fall into panel p all precede those of panel p + 1.  So
+//   * a workgroup owns a TILE of PAN_TR = 4096 rows whose running sums stay in LDS for the whole walk;
+//   * the tile's entries are stored panel-major — sorted by (panel, row, position in the row) — as 12 bytes each
+//     (row-in-tile << 19 | column-in-panel, value), cut into chunks of <= PAN_CH entries that never span two panels;
+//   * per chunk: all lanes load their entries (coalesced), gather x from the panel, park (value, x, row) in LDS; then
+//     the lane holding the FIRST entry of a row's run walks the run in order, starting from the row's running sum;
+//   * tiles are dealt round-robin, all resident workgroups start at panel 0 and walk at about the same pace, so the
+//     panel they gather from (2^16 doubles = 512 KB by default) stays in each XCD's 4 MB L2.
+// Rows longer than PAN_LCUT entries are left out of the image: their runs inside one panel would be walked by one
+// lane while the workgroup waits (measured: slower than no blocking at all).  They get a wave each in a second launch
+// (spmv_long_kernel), whose partial sums are added to this kernel's.
+// Measured in the lab (tools/panellab.hip, profiles/r02_panellab.txt): 100 G entries/s for the rows of <= 128 entries.
+//
+// Epilogues: EPI_STORE (with or without the fused dot) and EPI_RESIDUAL — one running sum per row.  The fused Jacobi /
+// GS forms carry two chains per row (half the rows in flight per CU); they stay on the irregular-row kernel.
+// The image is built on the device at upload: 64-bit keys (tile, panel, row) per entry, one stable radix sort
+// (rocPRIM), one gather pass; chunk descriptors from the per-(tile, panel) counts on the host.
+#include "its_handle.h"
+#include "its_epilogue.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace its {
+
+static int pan_env(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static int g_pan_on = pan_env("ITS_SPMV_PANEL", 1);
+static int g_pan_min_cols = pan_env("ITS_SPMV_PANEL_MIN_COLS", 1 << 21);   // x of >= 16 MB: far beyond one XCD's L2
+static int g_pan_log2pw = pan_env("ITS_SPMV_PANEL_LOG2PW", 16);
+static int g_pan_grid = pan_env("ITS_SPMV_PANEL_GRID", 1024);              // 4 workgroups per CU (37 KB of LDS each)
+
+int panel_tune(const char *name, int value)
+{
+    if (!strcmp(name, "spmv_panel")) { if (value < 0 || value > 1) return -1; g_pan_on = value; return 0; }
+    if (!strcmp(name, "spmv_panel_min_cols")) { if (value < 1) return -1; g_pan_min_cols = value; return 0; }
+    if (!strcmp(name, "spmv_panel_log2pw")) { if (value < 4 || value > PAN_COLBITS) return -1; g_pan_log2pw = value; return 0; }
+    if (!strcmp(name, "spmv_panel_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_pan_grid = value; return 0; }
+    return -2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// image build
+// ---------------------------------------------------------------------------------------------------------------
+// one lane per row: sort key (tile, panel, row in tile) of every entry of a short row, ~0 for the entries of long rows
+// (they sort to the end and are dropped); entries per (tile, panel); flags[0] |= 1 when a row's columns do not ascend
+__global__ __launch_bounds__(ITS_BLOCK) void panel_mark_kernel(
+    int n_rows, const int *__restrict__ rp, const int *__restrict__ col, int log2pw, int P, int lcut,
+    unsigned long long *__restrict__ key, unsigned int *__restrict__ src, int *__restrict__ piece_cnt,
+    unsigned char *__restrict__ is_long, int *__restrict__ flags)
+{
+    const int row = blockIdx.x * ITS_BLOCK + threadIdx.x;
+    if (row >= n_rows) return;
+    const int j0 = rp[row], j1 = rp[row + 1];
+    const bool lng = j1 - j0 > lcut;
+    is_long[row] = lng;
+    const int tile = row / PAN_TR, r = row % PAN_TR;
+    int prev = -1; bool bad = false;
+    for (int j = j0; j < j1; ++j) {
+        const int c = col[j];
+        bad |= c < prev; prev = c;
+        src[j] = (unsigned int)j;
+        if (lng) { key[j] = ~0ull; continue; }
+        const int p = c >> log2pw;
+        key[j] = ((unsigned long long)tile << 27) | ((unsigned long long)p << 12) | (unsigned long long)r;
+        atomicAdd(&piece_cnt[(size_t)tile * P + p], 1);
+    }
+    if (bad) atomicOr(flags, 1);
+}
+
+__global__ __launch_bounds__(ITS_BLOCK) void panel_gather_kernel(
+    int64_t n_short, const unsigned long long *__restrict__ key, const unsigned int *__restrict__ src,
+    const int *__restrict__ col, const double *__restrict__ val, int log2pw, uint32_t *__restrict__ pkey, double *__restrict__ pval)
+{
+    const int64_t i = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    if (i >= n_short) return;
+    const unsigned int j = src[i];
+    pkey[i] = ((uint32_t)(key[i] & 4095ull) << PAN_COLBITS) | ((uint32_t)col[j] & ((1u << log2pw) - 1u));
+    pval[i] = val[j];
+}
+
+}  // namespace its
+
+using namespace its;
+
+// Builds the panel image of A when it is the kind of matrix the blocking is for; leaves A.pan_* empty otherwise.
+int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
+{
+    const int n = A.n_rows;
+    const int64_t nnz = A.nnz;
+    if (!g_pan_on || n < 1 || nnz < 1 || A.max_row_len <= IRR_ROW_LEN || A.n_cols < g_pan_min_cols) return ITS_OK;
+    const int log2pw = g_pan_log2pw;
+    const int64_t P64 = ((int64_t)A.n_cols + ((int64_t)1 << log2pw) - 1) >> log2pw;
+    const int n_tiles = (n + PAN_TR - 1) / PAN_TR;
+    if (P64 >= (1 << 15) || n_tiles >= (1 << 19) || (int64_t)n_tiles * P64 > ((int64_t)1 << 27)) return ITS_OK;
+    const int P = (int)P64;
+    // long rows and what the image would hold, from the host's row_ptr
+    std::vector<unsigned char> is_long((size_t)n);
+    std::vector<int> long_rows;
+    int64_t nnz_long = 0;
+    for (int i = 0; i < n; ++i) {
+        const int len = host_rp[i + 1] - host_rp[i];
+        is_long[i] = len > PAN_LCUT;
+        if (is_long[i]) { long_rows.push_back(i); nnz_long += len; }
+    }
+    // longest first (ties: ascending row): waves take the list round-robin, so the long walks start at once and the
+    // work per wave evens out
+    std::stable_sort(long_rows.begin(), long_rows.end(), [&](int x, int y) { return host_rp[x + 1] - host_rp[x] > host_rp[y + 1] - host_rp[y]; });
+    if (nnz_long * 2 > nnz) return ITS_OK;                       // mostly long rows: nothing to block
+    const int64_t n_short = nnz - nnz_long;
+    unsigned long long *key_in = nullptr, *key_out = nullptr;
+    unsigned int *src_in = nullptr, *src_out = nullptr;
+    int *piece_cnt = nullptr, *flags = nullptr;
+    void *tmp = nullptr;
+    auto cleanup = [&]() { dfree(key_in); dfree(key_out); dfree(src_in); dfree(src_out); dfree(piece_cnt); dfree(flags); if (tmp) { (void)hipFree(tmp); tmp = nullptr; } };
+#define PAN_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return ITS_EHIP; } } while (0)
+    const size_t n_pieces = (size_t)n_tiles * P;
+    if (dalloc(h, &key_in, (size_t)nnz) || dalloc(h, &key_out, (size_t)nnz) || dalloc(h, &src_in, (size_t)nnz) ||
+        dalloc(h, &src_out, (size_t)nnz) || dalloc(h, &piece_cnt, n_pieces) || dalloc(h, &flags, 4) || dalloc(h, &A.pan_long, (size_t)n)) { cleanup(); return ITS_EHIP; }
+    PAN_TRY(hipMemsetAsync(piece_cnt, 0, n_pieces * sizeof(int), h->stream));
+    PAN_TRY(hipMemsetAsync(flags, 0, 4 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(panel_mark_kernel, dim3((n + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, h->stream, n, A.row_ptr, A.col,
+                       log2pw, P, PAN_LCUT, key_in, src_in, piece_cnt, A.pan_long, flags);
+    PAN_TRY(hipGetLastError());
+    size_t tmp_bytes = 0;
+    PAN_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, key_out, src_in, src_out, (size_t)nnz, 0u, 46u, h->stream));
+    PAN_TRY(hipMalloc(&tmp, tmp_bytes + 256));
+    PAN_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, key_out, src_in, src_out, (size_t)nnz, 0u, 46u, h->stream));
+    std::vector<int> cnt(n_pieces);
+    int hflags[4] = {0, 0, 0, 0};
+    PAN_TRY(hipMemcpyAsync(cnt.data(), piece_cnt, n_pieces * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    PAN_TRY(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, h->stream));
+    PAN_TRY(hipStreamSynchronize(h->stream));
+    if (hflags[0] & 1) {                                         // a row whose columns do not ascend: panel order != CRS order
+        cleanup(); dfree(A.pan_long);
+        return ITS_OK;
+    }
+    // chunk descriptors: {first entry, entries | panel << 9}, pieces in (tile, panel) order = the sorted order
+    std::vector<int2> desc;
+    std::vector<int> tile_ptr((size_t)n_tiles + 1, 0);
+    desc.reserve(n_pieces + (size_t)(n_short / PAN_CH) + 16);
+    int64_t off = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        tile_ptr[t] = (int)desc.size();
+        for (int p = 0; p < P; ++p) {
+            const int c = cnt[(size_t)t * P + p];
+            for (int q = 0; q < c; q += PAN_CH) desc.push_back(make_int2((int)(off + q), std::min(PAN_CH, c - q) | (p << 9)));
+            off += c;
+        }
+    }
+    tile_ptr[n_tiles] = (int)desc.size();
+    if (off != n_short) { cleanup(); dfree(A.pan_long); FAIL(h, ITS_EHIP, "panel image: entry counts do not add up"); }
+    if (dalloc(h, &A.pan_key, (size_t)n_short) || dalloc(h, &A.pan_val, (size_t)n_short) || dalloc(h, &A.pan_desc, desc.size() + 2) ||
+        dalloc(h, &A.pan_tile_ptr, tile_ptr.size()) || dalloc(h, &A.pan_long_rows, long_rows.size())) { cleanup(); return ITS_EHIP; }
+    hipLaunchKernelGGL(panel_gather_kernel, dim3((unsigned)((n_short + ITS_BLOCK - 1) / ITS_BLOCK)), dim3(ITS_BLOCK), 0, h->stream,
+                       n_short, key_out, src_out, A.col, A.val, log2pw, A.pan_key, A.pan_val);
+    PAN_TRY(hipGetLastError());
+    // two descriptors of padding behind the list: the kernel's look-ahead reads them (entries = 0)
+    desc.push_back(make_int2(0, 0)); desc.push_back(make_int2(0, 0));
+    PAN_TRY(hipMemcpyAsync(A.pan_desc, desc.data(), desc.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    PAN_TRY(hipMemcpyAsync(A.pan_tile_ptr, tile_ptr.data(), tile_ptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (!long_rows.empty())
+        PAN_TRY(hipMemcpyAsync(A.pan_long_rows, long_rows.data(), long_rows.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    PAN_TRY(hipStreamSynchronize(h->stream));
+#undef PAN_TRY
+    cleanup();
+    A.pan_tiles = n_tiles; A.pan_n_long = (int)long_rows.size(); A.pan_log2pw = log2pw; A.pan_nnz = n_short;
+    A.pan_chunks = (int)desc.size() - 2;
+    return ITS_OK;
+}
+
+namespace its {
+
+// ---------------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------------
+template <int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
+    int n_rows, int n_tiles, const int *__restrict__ tile_ptr, const int2 *__restrict__ desc,
+    const uint32_t *__restrict__ key, const double *__restrict__ val, const unsigned char *__restrict__ is_long,
+    int log2pw, SpmvArgs a)
+{
+    constexpr int U = PAN_CH / ITS_BLOCK;
+    static_assert(U == 1, "one entry per lane per chunk");
+    __shared__ double s_acc[PAN_TR];
+    __shared__ double s_v[PAN_CH], s_x[PAN_CH];
+    __shared__ unsigned short s_row[PAN_CH];
+    __shared__ double s_red[4];
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    double lane_sum = 0.0, lane_max = 0.0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += G) {
+        for (int i = t; i < PAN_TR; i += ITS_BLOCK) s_acc[i] = 0.0;
+        const int d0 = tile_ptr[tile], d1 = tile_ptr[tile + 1];
+        // software pipeline over the tile's chunks: entries two chunks ahead, gathers one chunk ahead of the chains
+        uint32_t k0 = 0, k1 = 0; double v0 = 0.0, v1 = 0.0, x0 = 0.0;
+        int m0 = 0, m1 = 0, p1 = 0;
+        if (d0 < d1) {
+            const int2 ds = desc[d0];
+            m0 = ds.y & 511;
+            if (t < m0) { k0 = __builtin_nontemporal_load(key + ds.x + t); v0 = __builtin_nontemporal_load(val + ds.x + t); }
+            if (t < m0) x0 = a.x[((int64_t)(ds.y >> 9) << log2pw) + (k0 & PAN_COLMASK)];
+            if (d0 + 1 < d1) {
+                const int2 dn = desc[d0 + 1];
+                m1 = dn.y & 511; p1 = dn.y >> 9;
+                if (t < m1) { k1 = __builtin_nontemporal_load(key + dn.x + t); v1 = __builtin_nontemporal_load(val + dn.x + t); }
+            }
+        }
+        __syncthreads();                                      // running sums cleared (and the previous tile's epilogue done)
+        for (int d = d0; d < d1; ++d) {
+            if (t < m0) { s_v[t] = v0; s_x[t] = x0; s_row[t] = (unsigned short)(k0 >> PAN_COLBITS); }
+            const int m = m0;
+            __syncthreads();
+            // gathers of chunk d + 1 and loads of chunk d + 2 are in flight during the chains
+            if (t < m1) x0 = a.x[((int64_t)p1 << log2pw) + (k1 & PAN_COLMASK)];
+            k0 = k1; v0 = v1; m0 = m1;
+            m1 = 0;
+            if (d + 2 < d1) {
+                const int2 dn = desc[d + 2];
+                m1 = dn.y & 511; p1 = dn.y >> 9;
+                if (t < m1) { k1 = __builtin_nontemporal_load(key + dn.x + t); v1 = __builtin_nontemporal_load(val + dn.x + t); }
+            }
+            // chains: the lane that holds the first entry of a row's run walks it, in order, from the row's running sum
+            if (t < m) {
+                const int r = s_row[t];
+                if (t == 0 || s_row[t - 1] != r) {
+                    double acc = s_acc[r];
+                    int j = t;
+                    do { acc = fma(s_v[j], s_x[j], acc); ++j; } while (j < m && s_row[j] == r);
+                    s_acc[r] = acc;
+                }
+            }
+            __syncthreads();
+        }
+        // epilogue of the tile's rows (long rows belong to the launch that follows)
+        for (int i = t; i < PAN_TR; i += ITS_BLOCK) {
+            const int row = tile * PAN_TR + i;
+            if (row < n_rows && !is_long[row]) {
+                double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+                epi_operands<EPI, DOT>(a, row, e0, e1, e2);
+                const double outv = row_finish<EPI, DOT>(s_acc[i], 0.0, 0.0, e0, e1, e2, lane_sum, lane_max);
+                if (a.y) a.y[row] = outv;
+            }
+        }
+        __syncthreads();
+    }
+    if (DOT || EpiKind<EPI>::norm) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (t == 0 && a.part_sum) {
+            a.part_sum[blockIdx.x] = bs;
+            for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_sum[z] = 0.0;
+        }
+        if (EpiKind<EPI>::norm && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (t == 0) {
+                a.part_max[blockIdx.x] = bm;
+                for (int z = blockIdx.x + G; z < ITS_NPART; z += G) a.part_max[z] = 0.0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The rows left out of the image (> PAN_LCUT entries): one WAVE per row, rows dealt to the waves from a list sorted by
+// descending length.  The chain is serial by definition, so everything else is kept off it (as in sweep_long_kernel):
+// col/val of chunk c + 2 and the x gathers of chunk c + 1 are in flight while chunk c is walked out of a wave-private LDS
+// strip, whose reads run one batch of 8 ahead of the multiply-adds.  Partial sums are ADDED to the panel kernel's.
+// (One-row blocks on the irregular-row kernel, the first version: 574 us for the 12.7 M entries of the 36 K long rows of
+// the power-law matrix — one lane of 256 chains while a workgroup holds a row — and 883 us in multicolour order, where the
+// hub rows sit next to each other in the list.)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LONG_LPL = 8;                         // entries per lane per chunk
+constexpr int LONG_CHUNK = LONG_LPL * ITS_WAVE;     // 512 entries staged per trip
+
+template <int EPI, bool DOT>
+__global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
+    const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+    const int *__restrict__ rows, int n_long, SpmvArgs a)
+{
+    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][LONG_CHUNK + 8];
+    __shared__ double s_red[4];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int64_t wstride = (int64_t)gridDim.x * (ITS_BLOCK / ITS_WAVE);
+    double lane_sum = 0.0, lane_max = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x + (int64_t)w * gridDim.x; k < n_long; k += wstride) {
+        const int row = rows[k];
+        const int rj0 = rp[row], rj1 = rp[row + 1];
+        double acc = 0.0;
+        int cn[LONG_LPL]; double vn[LONG_LPL], vv[LONG_LPL], xg[LONG_LPL];
+#define LONG_LOAD_CV(c0v)                                                                 \
+        _Pragma("unroll") for (int u = 0; u < LONG_LPL; ++u) {                            \
+            const int e_ = (c0v) + l + ITS_WAVE * u;                                      \
+            cn[u] = e_ < rj1 ? col[e_] : 0;                                               \
+            vn[u] = e_ < rj1 ? val[e_] : 0.0;                                             \
+        }
+#define LONG_GATHER()                                                                     \
+        _Pragma("unroll") for (int u = 0; u < LONG_LPL; ++u) { vv[u] = vn[u]; xg[u] = a.x[cn[u]]; }
+        LONG_LOAD_CV(rj0)
+        LONG_GATHER()
+        LONG_LOAD_CV(rj0 + LONG_CHUNK)
+        for (int c0 = rj0; c0 < rj1; c0 += LONG_CHUNK) {
+#pragma unroll
+            for (int u = 0; u < LONG_LPL; ++u) s_vx[w][l + ITS_WAVE * u] = make_double2(vv[u], xg[u]);
+            LONG_GATHER()
+            LONG_LOAD_CV(c0 + 2 * LONG_CHUNK)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int ne = min(LONG_CHUNK, rj1 - c0);
+            {
+                double2 pa[8], pb[8];
+#define LONG_RD(S, qv) _Pragma("unroll") for (int u = 0; u < 8; ++u) S[u] = s_vx[w][(qv) + u];
+#define LONG_FMA(S, cnt) _Pragma("unroll") for (int u = 0; u < 8; ++u) if (u < (cnt)) acc = fma(S[u].x, S[u].y, acc);
+                int q = 0;
+                LONG_RD(pa, 0)
+                for (; q + 16 <= ne; q += 16) {
+                    LONG_RD(pb, q + 8)
+                    LONG_FMA(pa, 8)
+                    LONG_RD(pa, q + 16)
+                    LONG_FMA(pb, 8)
+                }
+                if (q + 8 <= ne) {
+                    LONG_RD(pb, q + 8)
+                    LONG_FMA(pa, 8)
+                    q += 8;
+                    LONG_FMA(pb, ne - q)
+                } else {
+                    LONG_FMA(pa, ne - q)
+                }
+#undef LONG_RD
+#undef LONG_FMA
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+#undef LONG_LOAD_CV
+#undef LONG_GATHER
+        if (l == 0) {
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+            epi_operands<EPI, DOT>(a, row, e0, e1, e2);
+            const double outv = row_finish<EPI, DOT>(acc, 0.0, 0.0, e0, e1, e2, lane_sum, lane_max);
+            if (a.y) a.y[row] = outv;
+        }
+    }
+    if (DOT || EpiKind<EPI>::norm) {
+        const double bs = block_sum(lane_sum, s_red);
+        if (threadIdx.x == 0 && a.part_sum) a.part_sum[blockIdx.x] += bs;
+        if (EpiKind<EPI>::norm && a.part_max) {
+            const double bm = block_max(lane_max, s_red);
+            if (threadIdx.x == 0) a.part_max[blockIdx.x] = fmax(a.part_max[blockIdx.x], bm);
+        }
+    }
+}
+
+bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epi)
+{
+    (void)a;
+    return g_pan_on && A.pan_key != nullptr && (epi == EPI_STORE || epi == EPI_RESIDUAL);
+}
+
+void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
+{
+    SpmvArgs a = a_in;
+    a.part_accum = 0;
+    int grid = g_pan_grid;
+    const int need = ((A.pan_tiles + 7) / 8) * 8;
+    if (grid > need) grid = need;
+    dim3 g(grid), b(ITS_BLOCK);
+#define ITS_LAUNCHP(E, D) \
+    hipLaunchKernelGGL((spmv_panel_kernel<E, D>), g, b, 0, s, A.n_rows, A.pan_tiles, A.pan_tile_ptr, A.pan_desc, A.pan_key, A.pan_val, \
+                       A.pan_long, A.pan_log2pw, a)
+    if (epi == EPI_STORE) { if (a.dotv) ITS_LAUNCHP(EPI_STORE, true); else ITS_LAUNCHP(EPI_STORE, false); }
+    else ITS_LAUNCHP(EPI_RESIDUAL, false);
+#undef ITS_LAUNCHP
+    // the rows left out of the image: one wave each, partial sums added to the ones above (its grid never exceeds the
+    // panel kernel's zero-filled ITS_NPART slots)
+    if (A.pan_n_long > 0) {
+        int gl = (A.pan_n_long + 3) / 4;
+        if (gl > ITS_NPART) gl = ITS_NPART;
+        dim3 g2(gl);
+#define ITS_LAUNCHL(E, D) \
+    hipLaunchKernelGGL((spmv_long_kernel<E, D>), g2, b, 0, s, A.row_ptr, A.col, A.val, A.pan_long_rows, A.pan_n_long, a)
+        if (epi == EPI_STORE) { if (a.dotv) ITS_LAUNCHL(EPI_STORE, true); else ITS_LAUNCHL(EPI_STORE, false); }
+        else ITS_LAUNCHL(EPI_RESIDUAL, false);
+#undef ITS_LAUNCHL
+    }
+}
+
+}  // namespace its

@@ -13,7 +13,10 @@ REPS = int(os.environ.get("REPS", "40"))
 ROUNDS = int(os.environ.get("ROUNDS", "2"))
 NZ = int(os.environ.get("NZ", "0")) or None
 MAT = os.environ.get("MAT", "lap7")
-if MAT == "cd27":
+if MAT == "pl":
+    rp, col, val = matgen.powerlaw(N)
+    print("power-law %d rows" % N, flush=True)
+elif MAT == "cd27":
     rp, col, val = matgen.convdiff3d_27pt(N)
     print("27-pt convection-diffusion %d^3" % N, flush=True)
 else:
@@ -27,9 +30,13 @@ xd = h.to_dev(np.random.default_rng(0).uniform(-1, 1, n)); yd = h.dev_alloc(8 * 
 cfgs = sys.argv[1:] or ["grid=1024,map=1,nt=0"]
 for rnd in range(ROUNDS):
     for cfg in cfgs:
+        reup = False
         for kv in cfg.split(","):
             k, v = kv.split("=")
             h.set_option("spmv_" + k, int(v))
+            reup |= k in ("panel_log2pw", "panel_min_cols")        # read when the image is built
+        if reup:
+            h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
         h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=5)
         ms = h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=REPS)
         msd = h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=REPS, with_dot=True)
