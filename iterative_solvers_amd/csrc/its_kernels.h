@@ -95,7 +95,7 @@ struct CsrDev {
     // (tile, panel, row, position in row) as (key, value); chunk descriptors {first entry, entries | panel << 9} of
     // tile t at pan_desc[pan_tile_ptr[t] .. pan_tile_ptr[t+1]); the longer rows, longest first, in pan_long_rows
     uint32_t *pan_key = nullptr; double *pan_val = nullptr; int2 *pan_desc = nullptr; int *pan_tile_ptr = nullptr;
-    unsigned char *pan_long = nullptr; int *pan_long_rows = nullptr;
+    unsigned char *pan_long = nullptr; double *pan_diag = nullptr; int *pan_long_rows = nullptr;
     int pan_tiles = 0, pan_n_long = 0, pan_log2pw = 0, pan_chunks = 0;
     int64_t pan_nnz = 0;
     int64_t n_upper = 0;                      // entries with col > row (what a matching crs_U must hold)

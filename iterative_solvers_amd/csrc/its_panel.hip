@@ -19,8 +19,9 @@
 // (spmv_long_kernel), whose partial sums are added to this kernel's.
 // Measured in the lab (tools/panellab.hip, profiles/r02_panellab.txt): 100 G entries/s for the rows of <= 128 entries.
 //
-// Epilogues: EPI_STORE (with or without the fused dot) and EPI_RESIDUAL — one running sum per row.  The fused Jacobi /
-// GS forms carry two chains per row (half the rows in flight per CU); they stay on the irregular-row kernel.
+// Epilogues: EPI_STORE (with or without the fused dot), EPI_RESIDUAL, EPI_JACOBI_REF — one running sum per row — and
+// EPI_JACOBI_FUSED, which carries two chains per row: two running sums, 64 KB of LDS, half the rows in flight per CU.
+// The GS forms stay on the irregular-row kernel (the right-hand side pass runs over U, the sweeps over one colour of L).
 // The image is built on the device at upload: 64-bit keys (tile, panel, row) per entry, one stable radix sort
 // (rocPRIM), one gather pass; chunk descriptors from the per-(tile, panel) counts on the host.
 #include "its_handle.h"
@@ -55,10 +56,11 @@ int panel_tune(const char *name, int value)
 __global__ __launch_bounds__(ITS_BLOCK) void panel_mark_kernel(
     int n_rows, const int *__restrict__ rp, const int *__restrict__ col, int log2pw, int P, int lcut,
     unsigned long long *__restrict__ key, unsigned int *__restrict__ src, int *__restrict__ piece_cnt,
-    unsigned char *__restrict__ is_long, int *__restrict__ flags)
+    unsigned char *__restrict__ is_long, int *__restrict__ flags, const double *__restrict__ val, double *__restrict__ pdiag)
 {
     const int row = blockIdx.x * ITS_BLOCK + threadIdx.x;
     if (row >= n_rows) return;
+    double dgv = 0.0;                                   // what the chain's `diag = dg ? v : diag` ends with (its_epilogue.h)
     const int j0 = rp[row], j1 = rp[row + 1];
     const bool lng = j1 - j0 > lcut;
     is_long[row] = lng;
@@ -67,12 +69,14 @@ __global__ __launch_bounds__(ITS_BLOCK) void panel_mark_kernel(
     for (int j = j0; j < j1; ++j) {
         const int c = col[j];
         bad |= c < prev; prev = c;
+        if (c == row) dgv = val[j];
         src[j] = (unsigned int)j;
         if (lng) { key[j] = ~0ull; continue; }
         const int p = c >> log2pw;
         key[j] = ((unsigned long long)tile << 27) | ((unsigned long long)p << 12) | (unsigned long long)r;
         atomicAdd(&piece_cnt[(size_t)tile * P + p], 1);
     }
+    pdiag[row] = dgv;
     if (bad) atomicOr(flags, 1);
 }
 
@@ -124,11 +128,12 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
 #define PAN_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return ITS_EHIP; } } while (0)
     const size_t n_pieces = (size_t)n_tiles * P;
     if (dalloc(h, &key_in, (size_t)nnz) || dalloc(h, &key_out, (size_t)nnz) || dalloc(h, &src_in, (size_t)nnz) ||
-        dalloc(h, &src_out, (size_t)nnz) || dalloc(h, &piece_cnt, n_pieces) || dalloc(h, &flags, 4) || dalloc(h, &A.pan_long, (size_t)n)) { cleanup(); return ITS_EHIP; }
+        dalloc(h, &src_out, (size_t)nnz) || dalloc(h, &piece_cnt, n_pieces) || dalloc(h, &flags, 4) || dalloc(h, &A.pan_long, (size_t)n) ||
+        dalloc(h, &A.pan_diag, (size_t)n)) { cleanup(); return ITS_EHIP; }
     PAN_TRY(hipMemsetAsync(piece_cnt, 0, n_pieces * sizeof(int), h->stream));
     PAN_TRY(hipMemsetAsync(flags, 0, 4 * sizeof(int), h->stream));
     hipLaunchKernelGGL(panel_mark_kernel, dim3((n + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, h->stream, n, A.row_ptr, A.col,
-                       log2pw, P, PAN_LCUT, key_in, src_in, piece_cnt, A.pan_long, flags);
+                       log2pw, P, PAN_LCUT, key_in, src_in, piece_cnt, A.pan_long, flags, A.val, A.pan_diag);
     PAN_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
     PAN_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, key_out, src_in, src_out, (size_t)nnz, 0u, 46u, h->stream));
@@ -140,7 +145,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     PAN_TRY(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, h->stream));
     PAN_TRY(hipStreamSynchronize(h->stream));
     if (hflags[0] & 1) {                                         // a row whose columns do not ascend: panel order != CRS order
-        cleanup(); dfree(A.pan_long);
+        cleanup(); dfree(A.pan_long); dfree(A.pan_diag);
         return ITS_OK;
     }
     // chunk descriptors: {first entry, entries | panel << 9}, pieces in (tile, panel) order = the sorted order
@@ -157,7 +162,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
         }
     }
     tile_ptr[n_tiles] = (int)desc.size();
-    if (off != n_short) { cleanup(); dfree(A.pan_long); FAIL(h, ITS_EHIP, "panel image: entry counts do not add up"); }
+    if (off != n_short) { cleanup(); dfree(A.pan_long); dfree(A.pan_diag); FAIL(h, ITS_EHIP, "panel image: entry counts do not add up"); }
     if (dalloc(h, &A.pan_key, (size_t)n_short) || dalloc(h, &A.pan_val, (size_t)n_short) || dalloc(h, &A.pan_desc, desc.size() + 2) ||
         dalloc(h, &A.pan_tile_ptr, tile_ptr.size()) || dalloc(h, &A.pan_long_rows, long_rows.size())) { cleanup(); return ITS_EHIP; }
     hipLaunchKernelGGL(panel_gather_kernel, dim3((unsigned)((n_short + ITS_BLOCK - 1) / ITS_BLOCK)), dim3(ITS_BLOCK), 0, h->stream,
@@ -186,28 +191,32 @@ template <int EPI, bool DOT>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
     int n_rows, int n_tiles, const int *__restrict__ tile_ptr, const int2 *__restrict__ desc,
     const uint32_t *__restrict__ key, const double *__restrict__ val, const unsigned char *__restrict__ is_long,
-    int log2pw, SpmvArgs a)
+    const double *__restrict__ pdiag, int log2pw, SpmvArgs a)
 {
     constexpr int U = PAN_CH / ITS_BLOCK;
     static_assert(U == 1, "one entry per lane per chunk");
-    __shared__ double s_acc[PAN_TR];
+    // the fused forms carry two chains per row (its_epilogue.h): two running sums, half as many workgroups per CU
+    constexpr int NACC = EpiKind<EPI>::fused ? 2 : 1;
+    constexpr bool COLS = EpiKind<EPI>::needs_col;
+    __shared__ double s_acc[NACC * PAN_TR];
     __shared__ double s_v[PAN_CH], s_x[PAN_CH];
+    __shared__ int s_col[COLS ? PAN_CH : 1];
     __shared__ unsigned short s_row[PAN_CH];
     __shared__ double s_red[4];
     const int t = threadIdx.x;
     const int G = gridDim.x;
     double lane_sum = 0.0, lane_max = 0.0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += G) {
-        for (int i = t; i < PAN_TR; i += ITS_BLOCK) s_acc[i] = 0.0;
+        for (int i = t; i < NACC * PAN_TR; i += ITS_BLOCK) s_acc[i] = 0.0;
         const int d0 = tile_ptr[tile], d1 = tile_ptr[tile + 1];
         // software pipeline over the tile's chunks: entries two chunks ahead, gathers one chunk ahead of the chains
         uint32_t k0 = 0, k1 = 0; double v0 = 0.0, v1 = 0.0, x0 = 0.0;
-        int m0 = 0, m1 = 0, p1 = 0;
+        int m0 = 0, m1 = 0, p0 = 0, p1 = 0;
         if (d0 < d1) {
             const int2 ds = desc[d0];
-            m0 = ds.y & 511;
+            m0 = ds.y & 511; p0 = ds.y >> 9;
             if (t < m0) { k0 = __builtin_nontemporal_load(key + ds.x + t); v0 = __builtin_nontemporal_load(val + ds.x + t); }
-            if (t < m0) x0 = a.x[((int64_t)(ds.y >> 9) << log2pw) + (k0 & PAN_COLMASK)];
+            if (t < m0) x0 = a.x[((int64_t)p0 << log2pw) + (k0 & PAN_COLMASK)];
             if (d0 + 1 < d1) {
                 const int2 dn = desc[d0 + 1];
                 m1 = dn.y & 511; p1 = dn.y >> 9;
@@ -216,26 +225,31 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
         }
         __syncthreads();                                      // running sums cleared (and the previous tile's epilogue done)
         for (int d = d0; d < d1; ++d) {
-            if (t < m0) { s_v[t] = v0; s_x[t] = x0; s_row[t] = (unsigned short)(k0 >> PAN_COLBITS); }
+            if (t < m0) {
+                s_v[t] = v0; s_x[t] = x0; s_row[t] = (unsigned short)(k0 >> PAN_COLBITS);
+                if (COLS) s_col[t] = (int)(((int64_t)p0 << log2pw) + (k0 & PAN_COLMASK));
+            }
             const int m = m0;
             __syncthreads();
             // gathers of chunk d + 1 and loads of chunk d + 2 are in flight during the chains
             if (t < m1) x0 = a.x[((int64_t)p1 << log2pw) + (k1 & PAN_COLMASK)];
-            k0 = k1; v0 = v1; m0 = m1;
+            k0 = k1; v0 = v1; m0 = m1; p0 = p1;
             m1 = 0;
             if (d + 2 < d1) {
                 const int2 dn = desc[d + 2];
                 m1 = dn.y & 511; p1 = dn.y >> 9;
                 if (t < m1) { k1 = __builtin_nontemporal_load(key + dn.x + t); v1 = __builtin_nontemporal_load(val + dn.x + t); }
             }
-            // chains: the lane that holds the first entry of a row's run walks it, in order, from the row's running sum
+            // chains: the lane that holds the first entry of a row's run walks it, in order, from the row's running sums
             if (t < m) {
                 const int r = s_row[t];
                 if (t == 0 || s_row[t - 1] != r) {
-                    double acc = s_acc[r];
+                    const int row = tile * PAN_TR + r;
+                    double acc = s_acc[r], acc2 = NACC == 2 ? s_acc[PAN_TR + r] : 0.0, dg = 0.0;
                     int j = t;
-                    do { acc = fma(s_v[j], s_x[j], acc); ++j; } while (j < m && s_row[j] == r);
+                    do { chain_step<EPI>(COLS ? s_col[j] : 0, row, s_v[j], s_x[j], acc, acc2, dg); ++j; } while (j < m && s_row[j] == r);
                     s_acc[r] = acc;
+                    if (NACC == 2) s_acc[PAN_TR + r] = acc2;
                 }
             }
             __syncthreads();
@@ -246,7 +260,9 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
             if (row < n_rows && !is_long[row]) {
                 double e0 = 0.0, e1 = 0.0, e2 = 0.0;
                 epi_operands<EPI, DOT>(a, row, e0, e1, e2);
-                const double outv = row_finish<EPI, DOT>(s_acc[i], 0.0, 0.0, e0, e1, e2, lane_sum, lane_max);
+                // (the diagonal the Jacobi forms divide by: the row's last entry on the diagonal, noted at the image build)
+                const double dg = EpiKind<EPI>::skip_diag ? pdiag[row] : 0.0;
+                const double outv = row_finish<EPI, DOT>(s_acc[i], NACC == 2 ? s_acc[PAN_TR + i] : 0.0, dg, e0, e1, e2, lane_sum, lane_max);
                 if (a.y) a.y[row] = outv;
             }
         }
@@ -285,7 +301,9 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
     const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
     const int *__restrict__ rows, int n_long, SpmvArgs a)
 {
+    constexpr bool COLS = EpiKind<EPI>::needs_col;
     __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][LONG_CHUNK + 8];
+    __shared__ int s_c[COLS ? ITS_BLOCK / ITS_WAVE : 1][COLS ? LONG_CHUNK + 8 : 1];
     __shared__ double s_red[4];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int64_t wstride = (int64_t)gridDim.x * (ITS_BLOCK / ITS_WAVE);
@@ -293,8 +311,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
     for (int64_t k = (int64_t)blockIdx.x + (int64_t)w * gridDim.x; k < n_long; k += wstride) {
         const int row = rows[k];
         const int rj0 = rp[row], rj1 = rp[row + 1];
-        double acc = 0.0;
-        int cn[LONG_LPL]; double vn[LONG_LPL], vv[LONG_LPL], xg[LONG_LPL];
+        double acc = 0.0, acc2 = 0.0, dg = 0.0;
+        int cn[LONG_LPL], cc[LONG_LPL]; double vn[LONG_LPL], vv[LONG_LPL], xg[LONG_LPL];
 #define LONG_LOAD_CV(c0v)                                                                 \
         _Pragma("unroll") for (int u = 0; u < LONG_LPL; ++u) {                            \
             const int e_ = (c0v) + l + ITS_WAVE * u;                                      \
@@ -302,21 +320,24 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
             vn[u] = e_ < rj1 ? val[e_] : 0.0;                                             \
         }
 #define LONG_GATHER()                                                                     \
-        _Pragma("unroll") for (int u = 0; u < LONG_LPL; ++u) { vv[u] = vn[u]; xg[u] = a.x[cn[u]]; }
+        _Pragma("unroll") for (int u = 0; u < LONG_LPL; ++u) { vv[u] = vn[u]; cc[u] = cn[u]; xg[u] = a.x[cn[u]]; }
         LONG_LOAD_CV(rj0)
         LONG_GATHER()
         LONG_LOAD_CV(rj0 + LONG_CHUNK)
         for (int c0 = rj0; c0 < rj1; c0 += LONG_CHUNK) {
 #pragma unroll
-            for (int u = 0; u < LONG_LPL; ++u) s_vx[w][l + ITS_WAVE * u] = make_double2(vv[u], xg[u]);
+            for (int u = 0; u < LONG_LPL; ++u) {
+                s_vx[w][l + ITS_WAVE * u] = make_double2(vv[u], xg[u]);
+                if (COLS) s_c[w][l + ITS_WAVE * u] = cc[u];
+            }
             LONG_GATHER()
             LONG_LOAD_CV(c0 + 2 * LONG_CHUNK)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const int ne = min(LONG_CHUNK, rj1 - c0);
             {
-                double2 pa[8], pb[8];
-#define LONG_RD(S, qv) _Pragma("unroll") for (int u = 0; u < 8; ++u) S[u] = s_vx[w][(qv) + u];
-#define LONG_FMA(S, cnt) _Pragma("unroll") for (int u = 0; u < 8; ++u) if (u < (cnt)) acc = fma(S[u].x, S[u].y, acc);
+                double2 pa[8], pb[8]; int cpa[8], cpb[8]; (void)cpa; (void)cpb;
+#define LONG_RD(S, qv) _Pragma("unroll") for (int u = 0; u < 8; ++u) { S[u] = s_vx[w][(qv) + u]; if (COLS) c##S[u] = s_c[w][(qv) + u]; }
+#define LONG_FMA(S, cnt) _Pragma("unroll") for (int u = 0; u < 8; ++u) if (u < (cnt)) chain_step<EPI>(COLS ? c##S[u] : 0, row, S[u].x, S[u].y, acc, acc2, dg);
                 int q = 0;
                 LONG_RD(pa, 0)
                 for (; q + 16 <= ne; q += 16) {
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
         if (l == 0) {
             double e0 = 0.0, e1 = 0.0, e2 = 0.0;
             epi_operands<EPI, DOT>(a, row, e0, e1, e2);
-            const double outv = row_finish<EPI, DOT>(acc, 0.0, 0.0, e0, e1, e2, lane_sum, lane_max);
+            const double outv = row_finish<EPI, DOT>(acc, acc2, dg, e0, e1, e2, lane_sum, lane_max);
             if (a.y) a.y[row] = outv;
         }
     }
@@ -360,7 +381,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
 bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epi)
 {
     (void)a;
-    return g_pan_on && A.pan_key != nullptr && (epi == EPI_STORE || epi == EPI_RESIDUAL);
+    return g_pan_on && A.pan_key != nullptr &&
+           (epi == EPI_STORE || epi == EPI_RESIDUAL || epi == EPI_JACOBI_REF || epi == EPI_JACOBI_FUSED);
 }
 
 void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
@@ -368,14 +390,20 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
     SpmvArgs a = a_in;
     a.part_accum = 0;
     int grid = g_pan_grid;
+    if (epi == EPI_JACOBI_FUSED) grid = (grid / 16) * 8;         // two running sums per row: 64 KB of LDS, 2 workgroups per CU
+    if (grid < 8) grid = 8;
     const int need = ((A.pan_tiles + 7) / 8) * 8;
     if (grid > need) grid = need;
     dim3 g(grid), b(ITS_BLOCK);
 #define ITS_LAUNCHP(E, D) \
     hipLaunchKernelGGL((spmv_panel_kernel<E, D>), g, b, 0, s, A.n_rows, A.pan_tiles, A.pan_tile_ptr, A.pan_desc, A.pan_key, A.pan_val, \
-                       A.pan_long, A.pan_log2pw, a)
-    if (epi == EPI_STORE) { if (a.dotv) ITS_LAUNCHP(EPI_STORE, true); else ITS_LAUNCHP(EPI_STORE, false); }
-    else ITS_LAUNCHP(EPI_RESIDUAL, false);
+                       A.pan_long, A.pan_diag, A.pan_log2pw, a)
+    switch (epi) {
+    case EPI_STORE: if (a.dotv) ITS_LAUNCHP(EPI_STORE, true); else ITS_LAUNCHP(EPI_STORE, false); break;
+    case EPI_RESIDUAL: ITS_LAUNCHP(EPI_RESIDUAL, false); break;
+    case EPI_JACOBI_REF: ITS_LAUNCHP(EPI_JACOBI_REF, false); break;
+    default: ITS_LAUNCHP(EPI_JACOBI_FUSED, false); break;
+    }
 #undef ITS_LAUNCHP
     // the rows left out of the image: one wave each, partial sums added to the ones above (its grid never exceeds the
     // panel kernel's zero-filled ITS_NPART slots)
@@ -385,8 +413,12 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
         dim3 g2(gl);
 #define ITS_LAUNCHL(E, D) \
     hipLaunchKernelGGL((spmv_long_kernel<E, D>), g2, b, 0, s, A.row_ptr, A.col, A.val, A.pan_long_rows, A.pan_n_long, a)
-        if (epi == EPI_STORE) { if (a.dotv) ITS_LAUNCHL(EPI_STORE, true); else ITS_LAUNCHL(EPI_STORE, false); }
-        else ITS_LAUNCHL(EPI_RESIDUAL, false);
+        switch (epi) {
+        case EPI_STORE: if (a.dotv) ITS_LAUNCHL(EPI_STORE, true); else ITS_LAUNCHL(EPI_STORE, false); break;
+        case EPI_RESIDUAL: ITS_LAUNCHL(EPI_RESIDUAL, false); break;
+        case EPI_JACOBI_REF: ITS_LAUNCHL(EPI_JACOBI_REF, false); break;
+        default: ITS_LAUNCHL(EPI_JACOBI_FUSED, false); break;
+        }
 #undef ITS_LAUNCHL
     }
 }

@@ -25,14 +25,18 @@ def forced(gpu_handle):
     h.set_option("spmv_panel", 1)
 
 
-def heavy_tail(n, seed, max_len=3000, n_cols=None):
-    """rows of 1 .. max_len entries (Pareto tail), ascending distinct columns, some rows empty"""
+def heavy_tail(n, seed, max_len=3000, n_cols=None, diag=False):
+    """rows of 1 .. max_len entries (Pareto tail), ascending distinct columns, some rows empty (none with diag=True:
+    every row then holds its diagonal)"""
     rng = np.random.default_rng(seed)
     n_cols = n_cols or n
     rows = []
     for i in range(n):
-        ln = 0 if i % 23 == 7 else int(min(max_len, n_cols, 3.0 * rng.random() ** (-0.75)))
-        rows.append(np.sort(rng.choice(n_cols, ln, replace=False)))
+        ln = 0 if (i % 23 == 7 and not diag) else int(min(max_len, n_cols, 3.0 * rng.random() ** (-0.75)))
+        c = rng.choice(n_cols, ln, replace=False)
+        if diag:
+            c = np.union1d(c, [i])
+        rows.append(np.sort(c))
     rp = np.zeros(n + 1, np.int32); rp[1:] = np.cumsum([len(r) for r in rows])
     return rp, np.concatenate(rows).astype(np.int32), rng.uniform(-1, 1, int(rp[-1])), n_cols
 
@@ -141,3 +145,65 @@ def test_cg_history_identical_with_and_without_the_panel_image(forced):
     orc.set_threads(1)
     ref = orc.solve(rp, col, val, b, np.zeros(n), orc.CG, fixed_iters=12, max_iters=12)["all_values"][:12]
     assert np.all(np.abs(out[0][0] - ref) <= 1e-10 * ref)
+
+
+@pytest.mark.parametrize("n,log2pw,seed", [(4097, 6, 31), (20000, 9, 32)])
+def test_panel_jacobi_forms_bit_exact(forced, n, log2pw, seed):
+    """EPI_JACOBI_REF (one chain without the diagonal) and EPI_JACOBI_FUSED (that chain and the full one: two running sums
+    per row) store the same bits as the irregular-row kernel: its_spmv_timed modes 4 and 6 with b := x."""
+    h = forced
+    rp, col, val, _ = heavy_tail(n, seed, diag=True)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    val = np.where(col == rows, 5.0 + np.abs(val), val)
+    h.set_option("spmv_panel_log2pw", log2pw)
+    h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+    x = np.random.default_rng(seed).uniform(0.5, 1.5, n)
+    px = h.to_dev(x); py = h.dev_alloc(8 * n + 64)
+    outs = {}
+    try:
+        for pan in (1, 0):
+            h.set_option("spmv_panel", pan)
+            for mode in (4, 6):
+                h.check(h.L.its_memcpy_h2d(h.h, py, np.zeros(n).ctypes.data, 8 * n), "clear")
+                h.spmv_timed(px, py, capi.FMT_CSR_EXACT, reps=1, with_dot=mode)
+                outs[(pan, mode)] = h.from_dev(py, n)
+        for mode in (4, 6):
+            assert np.array_equal(outs[(1, mode)], outs[(0, mode)]), mode
+        # the sweep itself: x_i' = (b_i - sum_{j != i} a_ij x_j) / a_ii, chain in CRS order without the diagonal
+        off = np.where(col == rows, 0.0, val)
+        assert np.array_equal(outs[(1, 4)], (x - orc.spmv(rp, col, off, x)) / val[col == rows])
+    finally:
+        h.set_option("spmv_panel", 1)
+        h.dev_free(px); h.dev_free(py)
+
+
+def test_jacobi_solve_identical_iterate_with_the_panel_image(forced):
+    """Jacobi (correct sweep, one fused pass over A per trip) with and without the panel image: the iterate is a per-row
+    chain, so x after 15 trips is bit-identical; the recorded norms differ only by the grouping of the partial sums."""
+    n = 12000
+    rp, col, val, _ = heavy_tail(n, 41, max_len=1500, diag=True)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    val = 0.05 * val
+    dg = 1.0 + np.bincount(rows, weights=np.abs(val), minlength=n)
+    val = np.where(col == rows, dg[rows], val)
+    b = np.ones(n)
+    out = []
+    for pan in (1, 0):
+        args = S.Args("jacobi", S.LoopParams(max_iters=10**9, tol=0.0))
+        sol = S.Solver("jacobi", device=0, jacobi_mode=1)
+        try:
+            sol.handle.set_option("spmv_panel_min_cols", 1); sol.handle.set_option("spmv_panel_log2pw", 8)
+            sol.handle.set_option("spmv_panel", pan)
+            S.preprocessing_crs(args, sol, rp, col, val, b, np.zeros(n))
+            hist = np.array([sol.handle.iterate(it) for it in range(15)])
+            out.append((hist, sol.save_x_star(15).copy()))
+        finally:
+            sol.handle.set_option("spmv_panel", 1)
+            sol.handle.set_option("spmv_panel_min_cols", 1 << 21); sol.handle.set_option("spmv_panel_log2pw", 16)
+            sol.handle.close()
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.all(np.abs(out[0][0] - out[1][0]) <= 1e-13 * out[1][0][0])
+    orc.set_threads(1)
+    ref = orc.solve(rp, col, val, b, np.zeros(n), orc.JACOBI, jacobi_mode=1, fixed_iters=15, max_iters=15)
+    assert np.array_equal(out[0][1], ref["x_star"])
+    assert np.all(np.abs(out[0][0] - ref["all_values"][:15]) <= 1e-10 * ref["all_values"][:15])
