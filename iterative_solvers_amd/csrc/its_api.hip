@@ -387,8 +387,8 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         }
     }
     pt.lap("ELL image");
-    if (which == ITS_MAT_A) {
-        // column-panel blocked image for large irregular matrices (its_panel.hip)
+    if (which == ITS_MAT_A || which == ITS_MAT_U) {
+        // column-panel blocked image for large irregular matrices (its_panel.hip); crs_U for the b - U x pass of GS
         int rcp = build_panel_image(h, A, row_ptr);
         if (rcp) return rcp;
         pt.lap("panel image");

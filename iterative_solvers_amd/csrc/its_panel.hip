@@ -19,9 +19,10 @@
 // (spmv_long_kernel), whose partial sums are added to this kernel's.
 // Measured in the lab (tools/panellab.hip, profiles/r02_panellab.txt): 100 G entries/s for the rows of <= 128 entries.
 //
-// Epilogues: EPI_STORE (with or without the fused dot), EPI_RESIDUAL, EPI_JACOBI_REF — one running sum per row — and
+// Epilogues: EPI_STORE (with or without the fused dot), EPI_RESIDUAL, EPI_JACOBI_REF, EPI_GS_RHS (b - U x, over the image
+// of crs_U) — one running sum per row — and
 // EPI_JACOBI_FUSED, which carries two chains per row: two running sums, 64 KB of LDS, half the rows in flight per CU.
-// The GS forms stay on the irregular-row kernel (the right-hand side pass runs over U, the sweeps over one colour of L).
+// EPI_GS_FUSED and the sweeps stay on the irregular-row kernel (a sweep touches one colour of L at a time: no reuse).
 // The image is built on the device at upload: 64-bit keys (tile, panel, row) per entry, one stable radix sort
 // (rocPRIM), one gather pass; chunk descriptors from the per-(tile, panel) counts on the host.
 #include "its_handle.h"
@@ -382,7 +383,7 @@ bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epi)
 {
     (void)a;
     return g_pan_on && A.pan_key != nullptr &&
-           (epi == EPI_STORE || epi == EPI_RESIDUAL || epi == EPI_JACOBI_REF || epi == EPI_JACOBI_FUSED);
+           (epi == EPI_STORE || epi == EPI_RESIDUAL || epi == EPI_JACOBI_REF || epi == EPI_JACOBI_FUSED || epi == EPI_GS_RHS);
 }
 
 void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
@@ -402,6 +403,7 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
     case EPI_STORE: if (a.dotv) ITS_LAUNCHP(EPI_STORE, true); else ITS_LAUNCHP(EPI_STORE, false); break;
     case EPI_RESIDUAL: ITS_LAUNCHP(EPI_RESIDUAL, false); break;
     case EPI_JACOBI_REF: ITS_LAUNCHP(EPI_JACOBI_REF, false); break;
+    case EPI_GS_RHS: ITS_LAUNCHP(EPI_GS_RHS, false); break;
     default: ITS_LAUNCHP(EPI_JACOBI_FUSED, false); break;
     }
 #undef ITS_LAUNCHP
@@ -417,6 +419,7 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
         case EPI_STORE: if (a.dotv) ITS_LAUNCHL(EPI_STORE, true); else ITS_LAUNCHL(EPI_STORE, false); break;
         case EPI_RESIDUAL: ITS_LAUNCHL(EPI_RESIDUAL, false); break;
         case EPI_JACOBI_REF: ITS_LAUNCHL(EPI_JACOBI_REF, false); break;
+        case EPI_GS_RHS: ITS_LAUNCHL(EPI_GS_RHS, false); break;
         default: ITS_LAUNCHL(EPI_JACOBI_FUSED, false); break;
         }
 #undef ITS_LAUNCHL
