@@ -103,7 +103,9 @@ def cpu_baseline(rp, col, val, n, budget_s=15.0):
 
 
 GATHER_PEAK = 56.5e9      # random 8-byte gathers/s from an 80 MB table (Infinity Cache resident, not L2): measured ceiling
-                          # of MI355X, independent of occupancy and unrolling (tools/gatherlab.hip, profiles/r02_gatherlab.txt)
+                          # of MI355X, independent of occupancy and unrolling (tools/gatherlab.hip, profiles/r02_gatherlab.txt).
+                          # The column-panel blocked kernels (csrc/its_panel.hip) serve part of the gathers from L2 instead
+                          # (200 G/s from an L2-resident table): frac_gather_peak above 1 means exactly that.
 
 
 def other_configs(capi, matgen, S):
@@ -173,13 +175,14 @@ def other_configs(capi, matgen, S):
                         + (f", multicolour sweep with {sol.n_colors} colours" if sol.n_colors else ", correct sweep fused with the residual pass"),
             "ms_per_trip": dt * 1e3, "trips_per_s": 1 / dt, "algorithmic_bytes_per_trip": by,
             "GBps_algorithmic": by / dt / 1e9, "frac_hbm_peak": by / dt / 1e9 / HBM_PEAK_GBS,
-            "bound": "random gathers of x (80 MB: Infinity Cache, not L2)", "gathers_per_trip": gathers,
+            "bound": "random gathers of x (80 MB: Infinity Cache, not L2; the panel-blocked passes get part of them from L2)",
+            "kernel_of_the_pass_over_A": h.spmv_kernel_info(capi.MAT_A)[0], "gathers_per_trip": gathers,
             "frac_gather_peak": gathers / dt / GATHER_PEAK, "setup_seconds": setup, "generate_seconds": gen}
         if name == "jacobi":
             xd = h.to_dev(np.ones(n)); yd = h.dev_alloc(8 * n)
             h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=3)
             ms = h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=20)
-            res["c4_powerlaw_spmv_exact"] = {"ms": ms, "GBps_algorithmic": spmv_bytes(n, nnz) / ms / 1e6,
+            res["c4_powerlaw_spmv_exact"] = {"ms": ms, "kernel": h.spmv_kernel_info(capi.MAT_A)[0], "GBps_algorithmic": spmv_bytes(n, nnz) / ms / 1e6,
                                              "frac_hbm_peak": spmv_bytes(n, nnz) / ms / 1e6 / HBM_PEAK_GBS,
                                              "frac_gather_peak": nnz / (ms * 1e-3) / GATHER_PEAK}
         h.close()

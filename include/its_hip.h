@@ -112,6 +112,12 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *   "spmv_ell_map" 1 (default) = row blocks dealt to the XCDs by their position inside the far band's period
  *   "spmv_ell_wide" 1 (default) = rows of <= 32 entries with <= 255 distinct col - row (27-point stencils) run on the
  *                  byte-index form of that image (8 W + 4 ceil(W/4) bytes per row); "spmv_ellw_grid" workgroups (768)
+ *   "spmv_panel"   1 (default) = irregular matrices (longest row > 32) with at least "spmv_panel_min_cols" columns
+ *                  (default 2^21: an x of 16 MB) and ascending columns in every row also get a column-panel blocked
+ *                  image at upload (its_panel.hip: panels of 2^"spmv_panel_log2pw" doubles, default 16), so that the x
+ *                  gathers of whole-matrix products hit L2; used for the plain, CG, residual, Jacobi and (image of
+ *                  crs_U) Gauss-Seidel right-hand-side forms; 0 = the irregular-row kernel.  The two size options are
+ *                  read when a matrix is uploaded.  "spmv_panel_grid" workgroups (1024)
  *   "spmv_irr"     1 (default) = two-phase kernel when the longest row exceeds 32 entries
  *   "spmv_variant" 4 (default) | 5 | 2, "spmv_grid", "spmv_irr_grid", "spmv_irr_len", "spmv_map" 0|1:
  *                  tuning knobs kept for A/B measurements (tools/spmv_ab.py) */
