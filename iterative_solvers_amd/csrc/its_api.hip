@@ -42,7 +42,7 @@ static void free_csr(CsrDev &A)
     dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc); dfree(A.blk_desc_big);
     dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict); dfree(A.vidx); dfree(A.val_dict);
     dfree(A.ell_val); dfree(A.ell_idx);
-    dfree(A.pan_key); dfree(A.pan_val); dfree(A.pan_desc); dfree(A.pan_tile_ptr); dfree(A.pan_long); dfree(A.pan_diag); dfree(A.pan_long_rows);
+    dfree(A.pan_key); dfree(A.pan_val); dfree(A.pan_desc); dfree(A.pan_tile_ptr); dfree(A.pan_tile_row); dfree(A.pan_long); dfree(A.pan_diag); dfree(A.pan_long_rows);
     dfree(A.mix_rp_d); dfree(A.mix_col_d); dfree(A.mix_val_d); dfree(A.mix_rp_s); dfree(A.mix_col_s); dfree(A.mix_val_s);
     A = CsrDev();
 }

@@ -93,8 +93,8 @@ struct CsrDev {
     int max_row_len = 0;                      // longest row: > IRR_ROW_LEN selects the irregular-row exact kernel
     // panel image (its_panel.hip; only for large irregular A): entries of the rows of <= PAN_LCUT entries sorted by
     // (tile, panel, row, position in row) as (key, value); chunk descriptors {first entry, entries | panel << 9} of
-    // tile t at pan_desc[pan_tile_ptr[t] .. pan_tile_ptr[t+1]); the longer rows, longest first, in pan_long_rows
-    uint32_t *pan_key = nullptr; double *pan_val = nullptr; int2 *pan_desc = nullptr; int *pan_tile_ptr = nullptr;
+    // tile t (rows pan_tile_row[t] .. pan_tile_row[t+1]) at pan_desc[pan_tile_ptr[t] .. pan_tile_ptr[t+1]); the longer rows, longest first, in pan_long_rows
+    uint32_t *pan_key = nullptr; double *pan_val = nullptr; int2 *pan_desc = nullptr; int *pan_tile_ptr = nullptr; int *pan_tile_row = nullptr;
     unsigned char *pan_long = nullptr; double *pan_diag = nullptr; int *pan_long_rows = nullptr;
     int pan_tiles = 0, pan_n_long = 0, pan_log2pw = 0, pan_chunks = 0;
     int64_t pan_nnz = 0;

@@ -7,7 +7,8 @@
 // How.  The bit-exactness contract (spmv_crs_cpu, kernels.hpp:380-409) fixes the ORDER of a row's multiply-adds, not
 // where its entries live.  If every row's columns ascend, walking x in column PANELS keeps each row's chain order: the
 // entries of a row that fall into panel p all precede those of panel p + 1.  So
-//   * a workgroup owns a TILE of PAN_TR = 4096 rows whose running sums stay in LDS for the whole walk;
+//   * a workgroup owns a TILE of up to PAN_TR = 4096 consecutive rows (fewer where rows are long: tiles hold about the same
+//     number of entries) whose running sums stay in LDS for the whole walk;
 //   * the tile's entries are stored panel-major — sorted by (panel, row, position in the row) — as 12 bytes each
 //     (row-in-tile << 19 | column-in-panel, value), cut into chunks of <= PAN_CH entries that never span two panels;
 //   * per chunk: all lanes load their entries (coalesced), gather x from the panel, park (value, x, row) in LDS; then
@@ -56,6 +57,7 @@ int panel_tune(const char *name, int value)
 // (they sort to the end and are dropped); entries per (tile, panel); flags[0] |= 1 when a row's columns do not ascend
 __global__ __launch_bounds__(ITS_BLOCK) void panel_mark_kernel(
     int n_rows, const int *__restrict__ rp, const int *__restrict__ col, int log2pw, int P, int lcut,
+    const int *__restrict__ tile_row, int n_tiles,
     unsigned long long *__restrict__ key, unsigned int *__restrict__ src, int *__restrict__ piece_cnt,
     unsigned char *__restrict__ is_long, int *__restrict__ flags, const double *__restrict__ val, double *__restrict__ pdiag)
 {
@@ -65,7 +67,9 @@ __global__ __launch_bounds__(ITS_BLOCK) void panel_mark_kernel(
     const int j0 = rp[row], j1 = rp[row + 1];
     const bool lng = j1 - j0 > lcut;
     is_long[row] = lng;
-    const int tile = row / PAN_TR, r = row % PAN_TR;
+    int tile = 0;                                        // last tile whose first row is <= row
+    for (int lo = 0, hi = n_tiles - 1; lo <= hi;) { const int mid = (lo + hi) >> 1; if (tile_row[mid] <= row) { tile = mid; lo = mid + 1; } else hi = mid - 1; }
+    const int r = row - tile_row[tile];
     int prev = -1; bool bad = false;
     for (int j = j0; j < j1; ++j) {
         const int c = col[j];
@@ -104,8 +108,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     if (!g_pan_on || n < 1 || nnz < 1 || A.max_row_len <= IRR_ROW_LEN || A.n_cols < g_pan_min_cols) return ITS_OK;
     const int log2pw = g_pan_log2pw;
     const int64_t P64 = ((int64_t)A.n_cols + ((int64_t)1 << log2pw) - 1) >> log2pw;
-    const int n_tiles = (n + PAN_TR - 1) / PAN_TR;
-    if (P64 >= (1 << 15) || n_tiles >= (1 << 19) || (int64_t)n_tiles * P64 > ((int64_t)1 << 27)) return ITS_OK;
+    if (P64 >= (1 << 15)) return ITS_OK;
     const int P = (int)P64;
     // long rows and what the image would hold, from the host's row_ptr
     std::vector<unsigned char> is_long((size_t)n);
@@ -121,6 +124,24 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     std::stable_sort(long_rows.begin(), long_rows.end(), [&](int x, int y) { return host_rp[x + 1] - host_rp[x] > host_rp[y + 1] - host_rp[y]; });
     if (nnz_long * 2 > nnz) return ITS_OK;                       // mostly long rows: nothing to block
     const int64_t n_short = nnz - nnz_long;
+    // Tiles: consecutive rows, at most PAN_TR of them (the running sums in LDS) and at most 1.25x the mean tile's entries,
+    // so that a stretch of longer rows (the late colours of a multicolour ordering: 130 K entries per 4096 rows against a
+    // mean of 29 K on the power-law matrix) becomes more, shorter tiles instead of a few workgroups' long tail
+    std::vector<int> tile_row(1, 0);
+    {
+        const int64_t full_tiles = ((int64_t)n + PAN_TR - 1) / PAN_TR;
+        const int64_t mean = (n_short + full_tiles - 1) / full_tiles;
+        const int64_t cap = std::max<int64_t>(mean + mean / 4, 4 * PAN_LCUT);
+        int64_t cur = 0; int rows_in = 0;
+        for (int i = 0; i < n; ++i) {
+            const int len = is_long[i] ? 0 : host_rp[i + 1] - host_rp[i];
+            if (rows_in == PAN_TR || (rows_in > 0 && cur + len > cap)) { tile_row.push_back(i); cur = 0; rows_in = 0; }
+            cur += len; ++rows_in;
+        }
+        tile_row.push_back(n);
+    }
+    const int n_tiles = (int)tile_row.size() - 1;
+    if (n_tiles >= (1 << 19) || (int64_t)n_tiles * P64 > ((int64_t)1 << 27)) return ITS_OK;
     unsigned long long *key_in = nullptr, *key_out = nullptr;
     unsigned int *src_in = nullptr, *src_out = nullptr;
     int *piece_cnt = nullptr, *flags = nullptr;
@@ -130,11 +151,12 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     const size_t n_pieces = (size_t)n_tiles * P;
     if (dalloc(h, &key_in, (size_t)nnz) || dalloc(h, &key_out, (size_t)nnz) || dalloc(h, &src_in, (size_t)nnz) ||
         dalloc(h, &src_out, (size_t)nnz) || dalloc(h, &piece_cnt, n_pieces) || dalloc(h, &flags, 4) || dalloc(h, &A.pan_long, (size_t)n) ||
-        dalloc(h, &A.pan_diag, (size_t)n)) { cleanup(); return ITS_EHIP; }
+        dalloc(h, &A.pan_diag, (size_t)n) || dalloc(h, &A.pan_tile_row, tile_row.size())) { cleanup(); return ITS_EHIP; }
+    PAN_TRY(hipMemcpyAsync(A.pan_tile_row, tile_row.data(), tile_row.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     PAN_TRY(hipMemsetAsync(piece_cnt, 0, n_pieces * sizeof(int), h->stream));
     PAN_TRY(hipMemsetAsync(flags, 0, 4 * sizeof(int), h->stream));
     hipLaunchKernelGGL(panel_mark_kernel, dim3((n + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, h->stream, n, A.row_ptr, A.col,
-                       log2pw, P, PAN_LCUT, key_in, src_in, piece_cnt, A.pan_long, flags, A.val, A.pan_diag);
+                       log2pw, P, PAN_LCUT, A.pan_tile_row, n_tiles, key_in, src_in, piece_cnt, A.pan_long, flags, A.val, A.pan_diag);
     PAN_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
     PAN_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, key_out, src_in, src_out, (size_t)nnz, 0u, 46u, h->stream));
@@ -146,7 +168,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     PAN_TRY(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, h->stream));
     PAN_TRY(hipStreamSynchronize(h->stream));
     if (hflags[0] & 1) {                                         // a row whose columns do not ascend: panel order != CRS order
-        cleanup(); dfree(A.pan_long); dfree(A.pan_diag);
+        cleanup(); dfree(A.pan_long); dfree(A.pan_diag); dfree(A.pan_tile_row);
         return ITS_OK;
     }
     // chunk descriptors: {first entry, entries | panel << 9}, pieces in (tile, panel) order = the sorted order
@@ -163,7 +185,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
         }
     }
     tile_ptr[n_tiles] = (int)desc.size();
-    if (off != n_short) { cleanup(); dfree(A.pan_long); dfree(A.pan_diag); FAIL(h, ITS_EHIP, "panel image: entry counts do not add up"); }
+    if (off != n_short) { cleanup(); dfree(A.pan_long); dfree(A.pan_diag); dfree(A.pan_tile_row); FAIL(h, ITS_EHIP, "panel image: entry counts do not add up"); }
     if (dalloc(h, &A.pan_key, (size_t)n_short) || dalloc(h, &A.pan_val, (size_t)n_short) || dalloc(h, &A.pan_desc, desc.size() + 2) ||
         dalloc(h, &A.pan_tile_ptr, tile_ptr.size()) || dalloc(h, &A.pan_long_rows, long_rows.size())) { cleanup(); return ITS_EHIP; }
     hipLaunchKernelGGL(panel_gather_kernel, dim3((unsigned)((n_short + ITS_BLOCK - 1) / ITS_BLOCK)), dim3(ITS_BLOCK), 0, h->stream,
@@ -190,7 +212,7 @@ namespace its {
 // ---------------------------------------------------------------------------------------------------------------
 template <int EPI, bool DOT>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
-    int n_rows, int n_tiles, const int *__restrict__ tile_ptr, const int2 *__restrict__ desc,
+    int n_rows, int n_tiles, const int *__restrict__ tile_row, const int *__restrict__ tile_ptr, const int2 *__restrict__ desc,
     const uint32_t *__restrict__ key, const double *__restrict__ val, const unsigned char *__restrict__ is_long,
     const double *__restrict__ pdiag, int log2pw, SpmvArgs a)
 {
@@ -210,6 +232,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
     for (int tile = blockIdx.x; tile < n_tiles; tile += G) {
         for (int i = t; i < NACC * PAN_TR; i += ITS_BLOCK) s_acc[i] = 0.0;
         const int d0 = tile_ptr[tile], d1 = tile_ptr[tile + 1];
+        const int trow0 = tile_row[tile], trows = tile_row[tile + 1] - trow0;
         // software pipeline over the tile's chunks: entries two chunks ahead, gathers one chunk ahead of the chains
         uint32_t k0 = 0, k1 = 0; double v0 = 0.0, v1 = 0.0, x0 = 0.0;
         int m0 = 0, m1 = 0, p0 = 0, p1 = 0;
@@ -245,7 +268,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
             if (t < m) {
                 const int r = s_row[t];
                 if (t == 0 || s_row[t - 1] != r) {
-                    const int row = tile * PAN_TR + r;
+                    const int row = trow0 + r;
                     double acc = s_acc[r], acc2 = NACC == 2 ? s_acc[PAN_TR + r] : 0.0, dg = 0.0;
                     int j = t;
                     do { chain_step<EPI>(COLS ? s_col[j] : 0, row, s_v[j], s_x[j], acc, acc2, dg); ++j; } while (j < m && s_row[j] == r);
@@ -256,9 +279,9 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
             __syncthreads();
         }
         // epilogue of the tile's rows (long rows belong to the launch that follows)
-        for (int i = t; i < PAN_TR; i += ITS_BLOCK) {
-            const int row = tile * PAN_TR + i;
-            if (row < n_rows && !is_long[row]) {
+        for (int i = t; i < trows; i += ITS_BLOCK) {
+            const int row = trow0 + i;
+            if (!is_long[row]) {
                 double e0 = 0.0, e1 = 0.0, e2 = 0.0;
                 epi_operands<EPI, DOT>(a, row, e0, e1, e2);
                 // (the diagonal the Jacobi forms divide by: the row's last entry on the diagonal, noted at the image build)
@@ -397,7 +420,7 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
     if (grid > need) grid = need;
     dim3 g(grid), b(ITS_BLOCK);
 #define ITS_LAUNCHP(E, D) \
-    hipLaunchKernelGGL((spmv_panel_kernel<E, D>), g, b, 0, s, A.n_rows, A.pan_tiles, A.pan_tile_ptr, A.pan_desc, A.pan_key, A.pan_val, \
+    hipLaunchKernelGGL((spmv_panel_kernel<E, D>), g, b, 0, s, A.n_rows, A.pan_tiles, A.pan_tile_row, A.pan_tile_ptr, A.pan_desc, A.pan_key, A.pan_val, \
                        A.pan_long, A.pan_diag, A.pan_log2pw, a)
     switch (epi) {
     case EPI_STORE: if (a.dotv) ITS_LAUNCHP(EPI_STORE, true); else ITS_LAUNCHP(EPI_STORE, false); break;
