@@ -990,11 +990,11 @@ static int trip_gs(its_handle *h, double *res_out)
     // compared): the residual pass over A then also yields b - U x_new for the next trip (EPI_GS_FUSED)
     // (not for matrices on the irregular-row kernel: its one-lane-per-row walk out of LDS is issue-bound, and the
     // per-entry column test of the second chain costs more there than the separate pass over U: 2.7 vs 2.3 ms on
-    // the power-law matrix in multicolour order)
+    // the power-law matrix in multicolour order; with the panel image of A the fused pass wins again)
     const CsrDev &Am = h->mat[ITS_MAT_A], &Um = h->mat[ITS_MAT_U];
     const bool fused = h->fused_residual && Um.nnz == Am.n_upper && Um.n_upper == Um.nnz &&
                        Um.upper_col_sum == Am.upper_col_sum && Um.upper_val_xor == Am.upper_val_xor &&
-                       Am.max_row_len <= IRR_ROW_LEN && !its_dist_active(h);
+                       (Am.max_row_len <= IRR_ROW_LEN || spmv_panel_eligible(Am, u, EPI_GS_FUSED)) && !its_dist_active(h);
     if (!(fused && h->ahead)) {
         if ((rc = spmv_dispatch(h, h->mat[ITS_MAT_U], u, EPI_GS_RHS, ITS_FMT_CSR_EXACT))) return rc;   // gauss_seidel.hpp:144,177
     }

@@ -22,8 +22,8 @@
 //
 // Epilogues: EPI_STORE (with or without the fused dot), EPI_RESIDUAL, EPI_JACOBI_REF, EPI_GS_RHS (b - U x, over the image
 // of crs_U) — one running sum per row — and
-// EPI_JACOBI_FUSED, which carries two chains per row: two running sums, 64 KB of LDS, half the rows in flight per CU.
-// EPI_GS_FUSED and the sweeps stay on the irregular-row kernel (a sweep touches one colour of L at a time: no reuse).
+// EPI_JACOBI_FUSED / EPI_GS_FUSED, which carry two chains per row: two running sums, 64 KB of LDS, half the rows in
+// flight per CU.  The sweeps stay on the irregular-row kernel (a sweep touches one colour of L at a time: no reuse).
 // The image is built on the device at upload: 64-bit keys (tile, panel, row) per entry, one stable radix sort
 // (rocPRIM), one gather pass; chunk descriptors from the per-(tile, panel) counts on the host.
 #include "its_handle.h"
@@ -406,7 +406,7 @@ bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epi)
 {
     (void)a;
     return g_pan_on && A.pan_key != nullptr &&
-           (epi == EPI_STORE || epi == EPI_RESIDUAL || epi == EPI_JACOBI_REF || epi == EPI_JACOBI_FUSED || epi == EPI_GS_RHS);
+           (epi == EPI_STORE || epi == EPI_RESIDUAL || epi == EPI_JACOBI_REF || epi == EPI_JACOBI_FUSED || epi == EPI_GS_RHS || epi == EPI_GS_FUSED);
 }
 
 void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
@@ -414,7 +414,7 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
     SpmvArgs a = a_in;
     a.part_accum = 0;
     int grid = g_pan_grid;
-    if (epi == EPI_JACOBI_FUSED) grid = (grid / 16) * 8;         // two running sums per row: 64 KB of LDS, 2 workgroups per CU
+    if (epi == EPI_JACOBI_FUSED || epi == EPI_GS_FUSED) grid = (grid / 16) * 8;         // two running sums per row: 64 KB of LDS, 2 workgroups per CU
     if (grid < 8) grid = 8;
     const int need = ((A.pan_tiles + 7) / 8) * 8;
     if (grid > need) grid = need;
@@ -427,6 +427,7 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
     case EPI_RESIDUAL: ITS_LAUNCHP(EPI_RESIDUAL, false); break;
     case EPI_JACOBI_REF: ITS_LAUNCHP(EPI_JACOBI_REF, false); break;
     case EPI_GS_RHS: ITS_LAUNCHP(EPI_GS_RHS, false); break;
+    case EPI_GS_FUSED: ITS_LAUNCHP(EPI_GS_FUSED, false); break;
     default: ITS_LAUNCHP(EPI_JACOBI_FUSED, false); break;
     }
 #undef ITS_LAUNCHP
@@ -443,6 +444,7 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
         case EPI_RESIDUAL: ITS_LAUNCHL(EPI_RESIDUAL, false); break;
         case EPI_JACOBI_REF: ITS_LAUNCHL(EPI_JACOBI_REF, false); break;
         case EPI_GS_RHS: ITS_LAUNCHL(EPI_GS_RHS, false); break;
+        case EPI_GS_FUSED: ITS_LAUNCHL(EPI_GS_FUSED, false); break;
         default: ITS_LAUNCHL(EPI_JACOBI_FUSED, false); break;
         }
 #undef ITS_LAUNCHL
