@@ -332,7 +332,11 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int64_t wstride = (int64_t)gridDim.x * (ITS_BLOCK / ITS_WAVE);
     double lane_sum = 0.0, lane_max = 0.0;
-    for (int64_t k = (int64_t)blockIdx.x + (int64_t)w * gridDim.x; k < n_long; k += wstride) {
+    // rank k of the list (longest first) goes to wave k % 4 of workgroup k / 4: the four waves of a workgroup sit on the
+    // four SIMDs of a CU, so the longest rows each get a SIMD of their own to start with and share it only with rows a
+    // thousand ranks further down (dealt the other way — wave 0 of every workgroup takes the top ranks — the longest walks
+    // all land on SIMD 0 of their CUs and time-slice each other: 275 us instead of the walk of one 8192-entry row)
+    for (int64_t k = (int64_t)blockIdx.x * (ITS_BLOCK / ITS_WAVE) + w; k < n_long; k += wstride) {
         const int row = rows[k];
         const int rj0 = rp[row], rj1 = rp[row + 1];
         double acc = 0.0, acc2 = 0.0, dg = 0.0;
