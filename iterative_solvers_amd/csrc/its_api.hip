@@ -389,8 +389,14 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     pt.lap("ELL image");
     if (which == ITS_MAT_A || which == ITS_MAT_U) {
         // column-panel blocked image for large irregular matrices (its_panel.hip); crs_U for the b - U x pass of GS
-        int rcp = build_panel_image(h, A, row_ptr);
-        if (rcp) return rcp;
+        // (the image is an extra: when it cannot be built — its 12 bytes per entry or the sort's 24 do not fit — the matrix
+        // stays on the irregular-row kernel)
+        if (build_panel_image(h, A, row_ptr) != ITS_OK) {
+            dfree(A.pan_key); dfree(A.pan_val); dfree(A.pan_desc); dfree(A.pan_tile_ptr); dfree(A.pan_tile_row);
+            dfree(A.pan_long); dfree(A.pan_diag); dfree(A.pan_long_rows);
+            A.pan_tiles = A.pan_n_long = A.pan_chunks = 0; A.pan_nnz = 0;
+            (void)hipGetLastError();
+        }
         pt.lap("panel image");
     }
     if (which == ITS_MAT_L) {
