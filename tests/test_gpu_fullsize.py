@@ -141,11 +141,11 @@ def test_gmres50_27pt_128cubed_history():
 
 @pytest.fixture(scope="module")
 def powerlaw2m():
-    return matgen.powerlaw(2_000_000)
+    return matgen.powerlaw(2_200_000)       # >= 2^21 columns: the panel-blocked image is built (csrc/its_panel.hip)
 
 
 def test_jacobi_powerlaw_2m_history_and_iterate(powerlaw2m):
-    """configs[3], Jacobi leg at 2 M rows (longest row 8192: the irregular-row kernel, one fused pass over A per trip):
+    """configs[3], Jacobi leg at 2.2 M rows (longest row 8192: the panel-blocked kernels, one fused pass over A per trip):
     the iterate is the per-row in-order chain of jacobi_iteration_ref_cpu, so x after 12 trips equals the oracle's bit
     for bit; the recorded norms are tree sums against sequential ones: 1e-10."""
     rp, col, val = powerlaw2m
@@ -160,6 +160,7 @@ def test_jacobi_powerlaw_2m_history_and_iterate(powerlaw2m):
     sol = S.Solver("jacobi", device=0, jacobi_mode=1)
     try:
         S.preprocessing_crs(args, sol, rp, col, val, b, x0.copy())
+        assert sol.handle.spmv_kernel_info(capi.MAT_A)[0] == "spmv_panel_kernel"
         got = np.array([sol.handle.iterate(it) for it in range(trips)])
         xs = sol.save_x_star(trips).copy()
     finally:
@@ -186,6 +187,7 @@ def test_gauss_seidel_multicolor_powerlaw_2m(powerlaw2m):
     try:
         S.preprocessing_crs(args, sol, rp, col, val, b, b.copy())
         assert sol.n_colors == nc and nc <= 32
+        assert sol.handle.spmv_kernel_info(capi.MAT_A)[0] == "spmv_panel_kernel"
         got = np.array([sol.handle.iterate(it) for it in range(trips)])
         xs = sol.save_x_star(trips).copy()
     finally:
@@ -194,3 +196,31 @@ def test_gauss_seidel_multicolor_powerlaw_2m(powerlaw2m):
     assert np.all(np.abs(got - want) <= 1e-10 * want), np.abs(got - want) / want
     x_ref = np.empty(n); x_ref[perm] = ref["x_star"]
     assert np.array_equal(xs, x_ref)
+
+
+def test_spmv_powerlaw_2m_panel_image_bit_exact(gpu_handle, powerlaw2m):
+    """the plain product, the CG form and the residual form on the panel image at its real sizes (2^16-column panels,
+    4096-row tiles, 128-entry cut): bit-exact against the oracle and the irregular-row kernel"""
+    rp, col, val = powerlaw2m
+    n = len(rp) - 1
+    h = gpu_handle
+    x = np.random.default_rng(10).uniform(-1, 1, n)
+    orc.set_threads(min(16, orc.num_threads()))
+    ref = orc.spmv(rp, col, val, x)
+    orc.set_threads(1)
+    h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+    assert h.spmv_kernel_info(capi.MAT_A)[0] == "spmv_panel_kernel"
+    assert np.array_equal(h.spmv_host(x, n, capi.MAT_A, capi.FMT_CSR_EXACT), ref)
+    px = h.to_dev(x); py = h.dev_alloc(8 * n + 64)
+    try:
+        outs = {}
+        for pan in (1, 0):
+            h.set_option("spmv_panel", pan)
+            for mode in (1, 2):
+                h.spmv_timed(px, py, capi.FMT_CSR_EXACT, reps=1, with_dot=mode)
+                outs[(pan, mode)] = h.from_dev(py, n)
+        assert np.array_equal(outs[(1, 1)], ref) and np.array_equal(outs[(0, 1)], ref)
+        assert np.array_equal(outs[(1, 2)], x - ref) and np.array_equal(outs[(0, 2)], x - ref)
+    finally:
+        h.set_option("spmv_panel", 1)
+        h.dev_free(px); h.dev_free(py)
