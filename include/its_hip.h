@@ -117,7 +117,9 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                  image at upload (its_panel.hip: panels of 2^"spmv_panel_log2pw" doubles, default 16), so that the x
  *                  gathers of whole-matrix products hit L2; used for the plain, CG, residual, Jacobi and (image of
  *                  crs_U) Gauss-Seidel right-hand-side forms; 0 = the irregular-row kernel.  The two size options are
- *                  read when a matrix is uploaded.  "spmv_panel_grid" workgroups (1024)
+ *                  read when a matrix is uploaded, as is "spmv_panel_lcut" (128: rows longer than this get a wave each instead of a
+ *                  place in the image; 64: 1.05 ms, 128: 0.95, 192: 0.96, 256: 0.99 on the 10 M-row power-law matrix).
+ *                  "spmv_panel_grid" workgroups (1024)
  *   "spmv_irr"     1 (default) = two-phase kernel when the longest row exceeds 32 entries
  *   "spmv_variant" 4 (default) | 5 | 2, "spmv_grid", "spmv_irr_grid", "spmv_irr_len", "spmv_map" 0|1:
  *                  tuning knobs kept for A/B measurements (tools/spmv_ab.py) */

@@ -39,6 +39,7 @@ static int pan_env(const char *name, int dflt) { const char *e = getenv(name); r
 static int g_pan_on = pan_env("ITS_SPMV_PANEL", 1);
 static int g_pan_min_cols = pan_env("ITS_SPMV_PANEL_MIN_COLS", 1 << 21);   // x of >= 16 MB: far beyond one XCD's L2
 static int g_pan_log2pw = pan_env("ITS_SPMV_PANEL_LOG2PW", 16);
+static int g_pan_lcut = pan_env("ITS_SPMV_PANEL_LCUT", PAN_LCUT);          // rows longer than this get a wave each (read at upload)
 static int g_pan_grid = pan_env("ITS_SPMV_PANEL_GRID", 1024);              // 4 workgroups per CU (37 KB of LDS each)
 
 int panel_tune(const char *name, int value)
@@ -46,6 +47,7 @@ int panel_tune(const char *name, int value)
     if (!strcmp(name, "spmv_panel")) { if (value < 0 || value > 1) return -1; g_pan_on = value; return 0; }
     if (!strcmp(name, "spmv_panel_min_cols")) { if (value < 1) return -1; g_pan_min_cols = value; return 0; }
     if (!strcmp(name, "spmv_panel_log2pw")) { if (value < 4 || value > PAN_COLBITS) return -1; g_pan_log2pw = value; return 0; }
+    if (!strcmp(name, "spmv_panel_lcut")) { if (value < 1 || value > 4096) return -1; g_pan_lcut = value; return 0; }
     if (!strcmp(name, "spmv_panel_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_pan_grid = value; return 0; }
     return -2;
 }
@@ -106,7 +108,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     const int n = A.n_rows;
     const int64_t nnz = A.nnz;
     if (!g_pan_on || n < 1 || nnz < 1 || A.max_row_len <= IRR_ROW_LEN || A.n_cols < g_pan_min_cols) return ITS_OK;
-    const int log2pw = g_pan_log2pw;
+    const int log2pw = g_pan_log2pw, lcut = g_pan_lcut;
     const int64_t P64 = ((int64_t)A.n_cols + ((int64_t)1 << log2pw) - 1) >> log2pw;
     if (P64 >= (1 << 15)) return ITS_OK;
     const int P = (int)P64;
@@ -116,7 +118,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     int64_t nnz_long = 0;
     for (int i = 0; i < n; ++i) {
         const int len = host_rp[i + 1] - host_rp[i];
-        is_long[i] = len > PAN_LCUT;
+        is_long[i] = len > lcut;
         if (is_long[i]) { long_rows.push_back(i); nnz_long += len; }
     }
     // longest first (ties: ascending row): waves take the list round-robin, so the long walks start at once and the
@@ -131,7 +133,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     {
         const int64_t full_tiles = ((int64_t)n + PAN_TR - 1) / PAN_TR;
         const int64_t mean = (n_short + full_tiles - 1) / full_tiles;
-        const int64_t cap = std::max<int64_t>(mean + mean / 4, 4 * PAN_LCUT);
+        const int64_t cap = std::max<int64_t>(mean + mean / 4, 4 * lcut);
         int64_t cur = 0; int rows_in = 0;
         for (int i = 0; i < n; ++i) {
             const int len = is_long[i] ? 0 : host_rp[i + 1] - host_rp[i];
@@ -156,7 +158,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     PAN_TRY(hipMemsetAsync(piece_cnt, 0, n_pieces * sizeof(int), h->stream));
     PAN_TRY(hipMemsetAsync(flags, 0, 4 * sizeof(int), h->stream));
     hipLaunchKernelGGL(panel_mark_kernel, dim3((n + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, h->stream, n, A.row_ptr, A.col,
-                       log2pw, P, PAN_LCUT, A.pan_tile_row, n_tiles, key_in, src_in, piece_cnt, A.pan_long, flags, A.val, A.pan_diag);
+                       log2pw, P, lcut, A.pan_tile_row, n_tiles, key_in, src_in, piece_cnt, A.pan_long, flags, A.val, A.pan_diag);
     PAN_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
     PAN_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, key_out, src_in, src_out, (size_t)nnz, 0u, 46u, h->stream));

@@ -34,7 +34,7 @@ for rnd in range(ROUNDS):
         for kv in cfg.split(","):
             k, v = kv.split("=")
             h.set_option("spmv_" + k, int(v))
-            reup |= k in ("panel_log2pw", "panel_min_cols")        # read when the image is built
+            reup |= k in ("panel_log2pw", "panel_min_cols", "panel_lcut")        # read when the image is built
         if reup:
             h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
         h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=5)
