@@ -244,3 +244,37 @@ def test_gauss_seidel_multicolor_identical_iterate_with_the_panel_image(forced):
     ref = orc.solve(rpp, cp, vp, b, np.zeros(n), orc.GAUSS_SEIDEL, fixed_iters=10, max_iters=10)
     x_ref = np.empty(n); x_ref[perm] = ref["x_star"]
     assert np.array_equal(out[0][1], x_ref)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_panel_fuzz(forced, seed):
+    """random shapes, panel widths and row-length cuts; columns ascend but may repeat (the sort is stable: equal columns keep
+    their CRS order); empty rows, rows longer than the cut, fewer rows than a tile, more columns than rows"""
+    h = forced
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([3, 70, 600, 4095, 4096, 4100, 9000, 15000]))
+    n_cols = n + int(rng.choice([0, 0, 17, 900]))
+    lcut = int(rng.choice([1, 8, 40, 128, 300]))
+    log2pw = int(rng.integers(4, 13))
+    rows = []
+    for i in range(n):
+        u = rng.random()
+        ln = 0 if u < 0.1 else int(min(2000, 2.0 * rng.random() ** (-0.9)))
+        c = np.sort(rng.integers(0, n_cols, ln))                      # repeats allowed
+        rows.append(c)
+    if max(len(r) for r in rows) <= 32:
+        rows[n // 2] = np.sort(rng.integers(0, n_cols, 40))
+    rp = np.zeros(n + 1, np.int32); rp[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate(rows).astype(np.int32)
+    val = rng.uniform(-1, 1, int(rp[-1]))
+    x = rng.uniform(-1, 1, n_cols)
+    h.set_option("spmv_panel_log2pw", log2pw); h.set_option("spmv_panel_lcut", lcut)
+    try:
+        h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT, n_cols=n_cols)
+        ln = np.diff(rp)
+        if ln[ln > lcut].sum() * 2 <= rp[-1]:
+            assert h.spmv_kernel_info(capi.MAT_A)[0] == "spmv_panel_kernel", (n, lcut, log2pw)
+        got = h.spmv_host(x, n, capi.MAT_A, capi.FMT_CSR_EXACT)
+        assert np.array_equal(got, orc.spmv(rp, col, val, x)), (n, n_cols, lcut, log2pw)
+    finally:
+        h.set_option("spmv_panel_lcut", 128)
