@@ -1032,7 +1032,11 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     const bool use_copy = readback_mode() == 2;
     const bool hcol_pinned = !use_copy;
     double *hcol_out = hcol_pinned ? h->pinned + h->pin_h : h->hcol_dev;
-    if (hcol_pinned) arm_pinned_word(hcol_out + (k + 1));
+    // every entry of the column is armed, not only the last one: the entries come from k + 2 different kernels, and that
+    // the host sees their writes in launch order is an assumption about the path from the XCDs to host memory that one
+    // run in some hundreds did not keep (a stale H entry from the previous trip: its_solve -gm on lap3d_16 printed
+    // 2.38e-6 instead of 1.75e-6 at trip 36 once in a full-suite run and never in 32 repeats)
+    if (hcol_pinned) for (int i = 0; i <= k + 1; ++i) arm_pinned_word(hcol_out + i);
     const double *prev_part = nullptr; int prev_scalar = 0;
     if (h->gmres_ortho == 1) {
         // CGS-2 ("gmres_ortho" 1): h1 = V^T w, w -= V h1, h2 = V^T w, w -= V h2, H[:,k] = h1 + h2 — every product
@@ -1067,6 +1071,9 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     if (hcol_pinned) {
         // H[k+1,k] comes from the last kernel of the trip; the entries above it from kernels that finished before
         if ((rc = wait_pinned_word(h, hcol_out + (k + 1)))) return rc;
+        for (int i = 0; i <= k; ++i)                                       // (arrived long ago in all but the rare case)
+            if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + i) == kPendingWord && (rc = wait_pinned_word(h, hcol_out + i))) return rc;
+        std::atomic_thread_fence(std::memory_order_acquire);
         for (int i = 0; i <= k + 1; ++i) hc[i] = hcol_out[i];
     } else {
         HIPCHK(h, hipMemcpyAsync(h->pinned + h->pin_copy, h->hcol_dev, (size_t)(k + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
