@@ -1033,10 +1033,11 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     const bool hcol_pinned = !use_copy;
     double *hcol_out = hcol_pinned ? h->pinned + h->pin_h : h->hcol_dev;
     // every entry of the column is armed, not only the last one: the entries come from k + 2 different kernels, and that
-    // the host sees their writes in launch order is an assumption about the path from the XCDs to host memory that one
-    // run in some hundreds did not keep (a stale H entry from the previous trip: its_solve -gm on lap3d_16 printed
-    // 2.38e-6 instead of 1.75e-6 at trip 36 once in a full-suite run and never in 32 repeats)
-    if (hcol_pinned) for (int i = 0; i <= k + 1; ++i) arm_pinned_word(hcol_out + i);
+    // the host sees their writes in launch order is an assumption about the path from the XCDs to host memory.  (One
+    // its_solve -gm run printed a history that a stale entry of the previous column would explain; never reproduced
+    // — DESIGN.md §4 — but the assumption is not needed.)
+    static const bool arm_last_only = getenv("ITS_GMRES_ARM_LAST_ONLY") != nullptr;     // the old protocol, for A/B runs of tools/repeat_cli.sh
+    if (hcol_pinned) for (int i = arm_last_only ? k + 1 : 0; i <= k + 1; ++i) arm_pinned_word(hcol_out + i);
     const double *prev_part = nullptr; int prev_scalar = 0;
     if (h->gmres_ortho == 1) {
         // CGS-2 ("gmres_ortho" 1): h1 = V^T w, w -= V h1, h2 = V^T w, w -= V h2, H[:,k] = h1 + h2 — every product
