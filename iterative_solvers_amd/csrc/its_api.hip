@@ -274,7 +274,7 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     if (which == ITS_MAT_L) {                     // the sweep schedule describes the old L
         dfree(h->level_rows); dfree(h->sweep_desc);
         dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D); h->sw_w = 0;
-        h->n_levels = 0; h->level_ptr.clear(); h->level_nshort.clear(); h->level_desc_first.clear(); h->level_desc_count.clear();
+        h->n_levels = 0; h->level_ptr.clear(); h->level_nshort.clear(); h->level_desc_first.clear(); h->level_desc_count.clear(); h->level_empty_lo.clear();
         h->L_rp.clear(); h->L_maxcol.clear();
     }
     free_csr(A);
@@ -669,7 +669,7 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
     // those rows of L with the sweep's epilogue: it gets row-block descriptors of its own (blocks end at the
     // level's end) and runs on the exact stream kernels.  Levels of the natural order are scattered rows: they
     // keep the level-list kernel.
-    h->level_desc_first.assign(nl, 0); h->level_desc_count.assign(nl, 0);
+    h->level_desc_first.assign(nl, 0); h->level_desc_count.assign(nl, 0); h->level_empty_lo.assign(nl, -1);
     std::vector<int4> desc;
     std::vector<int> blk;
     for (int l = 0; l < nl; ++l) {
@@ -678,6 +678,8 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
         int lo = rows[b0], hi = rows[b0];
         for (int k = b0; k < b0 + cnt; ++k) { lo = std::min(lo, rows[k]); hi = std::max(hi, rows[k]); }
         if (hi - lo + 1 != cnt) continue;
+        // (the first colour of a multicolour ordering: no row reads anything, x = rhs / D is all there is to do)
+        if (Lp[lo + cnt] == Lp[lo]) { h->level_empty_lo[l] = lo; continue; }
         build_stream_plan(cnt, Lp + lo, blk);              // row indices relative to lo
         h->level_desc_first[l] = (int)desc.size();
         const int nbl = h->level_desc_count[l] = (int)blk.size() - 1;
@@ -722,7 +724,7 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
     {
         const CsrDev &L = h->mat[ITS_MAT_L];
         int n_list = 0;
-        for (int l = 0; l < nl; ++l) n_list += h->level_desc_count[l] == 0;
+        for (int l = 0; l < nl; ++l) n_list += h->level_desc_count[l] == 0 && h->level_empty_lo[l] < 0;
         if (h->sweep_ell && h->D && n > 0 && nl >= 32 && n_list * 2 >= nl && L.max_row_len >= 1 && L.max_row_len <= SWEEP_ELL_W) {
             const int W = L.max_row_len;
             if (dalloc(h, &h->sw_col, (size_t)W * n) || dalloc(h, &h->sw_val, (size_t)W * n) || dalloc(h, &h->sw_D, (size_t)n)) return ITS_EHIP;
@@ -742,7 +744,10 @@ static int sweep(its_handle *h, double *x, const double *rhs)
     const bool dist = its_dist_active(h);
     for (int l = 0; l < h->n_levels; ++l) {
         const int cnt = h->level_ptr[l + 1] - h->level_ptr[l];
-        if (h->level_desc_count[l] > 0 && h->sweep_stream) {
+        if (h->level_empty_lo[l] >= 0 && h->sweep_stream) {
+            const int lo = h->level_empty_lo[l];
+            launch_sweep_empty(x + lo, rhs + lo, h->D + lo, cnt, h->stream);
+        } else if (h->level_desc_count[l] > 0 && h->sweep_stream) {
             SpmvArgs a; a.x = x; a.y = x; a.b = rhs; a.D = h->D;   // rows of a level never read each other's x
             launch_spmv_exact_desc(L, h->sweep_desc + h->level_desc_first[l], h->level_desc_count[l], a, EPI_SWEEP, 0, h->stream);
         } else if (h->sw_w > 0 && h->sweep_ell) {

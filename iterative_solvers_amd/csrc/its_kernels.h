@@ -129,6 +129,7 @@ void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStre
 // launch tunables of the exact SpMV ("spmv_grid", "spmv_map", "spmv_variant", "spmv_idx", "spmv_valdict", "spmv_irr",
 // "spmv_irr_len", "spmv_irr_grid", "spmv_bigplan"); 0 ok, -1 bad value, -2 unknown name
 int spmv_tune(const char *name, int value);
+void launch_sweep_empty(double *x, const double *rhs, const double *D, int64_t n, hipStream_t s);   // level without entries in L
 void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const SpmvArgs &a, int epilogue,
                             int accumulate, hipStream_t s);
 // true when this launch would walk CsrDev::blk_desc_big (callers that pass descriptor lists of their own must

@@ -1299,6 +1299,17 @@ void launch_sqrt_scalar(const double *in, double *out, hipStream_t s)
 { hipLaunchKernelGGL(sqrt_scalar_kernel, dim3(1), dim3(1), 0, s, in, out); }
 void launch_axpby(double *out, const double *a, const double *b, int64_t n, double sc, hipStream_t s)
 { hipLaunchKernelGGL(axpby_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, out, a, b, n, sc); }
+// a sweep level whose rows have no entries in L: x_i = (rhs_i - 0.0) / D_i, the value the chain kernels give for an empty
+// row (rhs - (+0.0) == rhs bit for bit)
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_empty_kernel(double *x, const double *rhs, const double *__restrict__ D, int64_t n)
+{
+    const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
+    for (int64_t i = tid; i < n; i += nth) x[i] = (rhs[i] - 0.0) / D[i];
+}
+void launch_sweep_empty(double *x, const double *rhs, const double *D, int64_t n, hipStream_t s)
+{ hipLaunchKernelGGL(sweep_empty_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, x, rhs, D, n); }
+
 void launch_scale(double *out, const double *v, double sc, int64_t n, hipStream_t s)
 { hipLaunchKernelGGL(scale_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, out, v, sc, n); }
 void launch_copy(double *out, const double *v, int64_t n, hipStream_t s)
