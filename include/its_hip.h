@@ -100,6 +100,9 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                  stream beside the interior row blocks, boundary blocks afterwards.  Same values.
  *   "sweep_stream" 1 (default) = sweep levels that are contiguous row ranges (the colours of a multicolour
  *                  ordering) run on the exact SpMV kernels; 0 = level-list kernels only.  Same bits.
+ *   "sweep_ell_levels" 1 (default) = such a level gets an ELL image of its own rows of crs_L when they are short and
+ *                  regular (colours of a stencil: nibble or byte dictionary indices, as for "spmv_ell"), built at
+ *                  its_solver_setup; a level whose rows have no entries is one elementwise kernel.  Same bits.
  * Process-wide launch options of the exact SpMV (any time; all lossless, results bit-identical):
  *   "spmv_idx"     1 (default) = stream the 1-byte column-offset dictionary index instead of the 4-byte
  *                  column when the matrix has <= 256 distinct col - row; 0 = always the plain col stream

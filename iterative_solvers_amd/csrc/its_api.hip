@@ -37,6 +37,12 @@ struct PhaseTimer {
 
 int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp);    // its_panel.hip
 
+static void free_level_ell(its_handle *h)
+{
+    for (auto &v : h->level_ell) { dfree(v.val); dfree(v.idx); }
+    h->level_ell.clear();
+}
+
 static void free_csr(CsrDev &A)
 {
     dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc); dfree(A.blk_desc_big);
@@ -124,7 +130,7 @@ extern "C" int its_destroy(its_handle *h)
     dfree(h->pcg_w); dfree(h->pcg_s); dfree(h->pcg_z); dfree(h->pcg_pair[0]); dfree(h->pcg_pair[1]); dfree(h->gram_part); dfree(h->gram_h);
     for (auto &e : h->prof_ev) (void)hipEventDestroy(e);
     for (auto &p : h->part) dfree(p);
-    dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows); dfree(h->sweep_desc);
+    dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows); dfree(h->sweep_desc); free_level_ell(h);
     dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D);
     if (h->pinned) (void)hipHostFree(h->pinned);
     (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
@@ -272,7 +278,7 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     h->setup_done = false; h->ahead = false;
     if (which == ITS_MAT_A) h->residual_done = false;
     if (which == ITS_MAT_L) {                     // the sweep schedule describes the old L
-        dfree(h->level_rows); dfree(h->sweep_desc);
+        dfree(h->level_rows); dfree(h->sweep_desc); free_level_ell(h);
         dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D); h->sw_w = 0;
         h->n_levels = 0; h->level_ptr.clear(); h->level_nshort.clear(); h->level_desc_first.clear(); h->level_desc_count.clear(); h->level_empty_lo.clear();
         h->L_rp.clear(); h->L_maxcol.clear();
@@ -478,6 +484,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->watch_window_ms = value; h->watch_misses = 0;
         return ITS_OK;
     }
+    if (!strcmp(name, "sweep_ell_levels")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_ell_levels: 0 or 1");
+        h->sweep_ell_levels = value;
+        return ITS_OK;
+    }
     if (!strcmp(name, "sweep_ell")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_ell: 0 or 1");
         h->sweep_ell = value;
@@ -670,6 +681,7 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
     // level's end) and runs on the exact stream kernels.  Levels of the natural order are scattered rows: they
     // keep the level-list kernel.
     h->level_desc_first.assign(nl, 0); h->level_desc_count.assign(nl, 0); h->level_empty_lo.assign(nl, -1);
+    free_level_ell(h); h->level_ell.assign(nl, SweepEll());
     std::vector<int4> desc;
     std::vector<int> blk;
     for (int l = 0; l < nl; ++l) {
@@ -680,6 +692,30 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
         if (hi - lo + 1 != cnt) continue;
         // (the first colour of a multicolour ordering: no row reads anything, x = rhs / D is all there is to do)
         if (Lp[lo + cnt] == Lp[lo]) { h->level_empty_lo[l] = lo; continue; }
+        // The level as an ELL image of its own (its_ell.hip) when its rows are short and regular: values slot-major, 4- or
+        // 8-bit dictionary indices, no row_ptr stream — the colours of a stencil in multicolour order (7-pt: 7 distinct
+        // offsets, rows of 6; 27-pt: 52 offsets, rows of <= 26).  Needs the offset dictionary of L and 16-byte aligned slices.
+        {
+            const CsrDev &L = h->mat[ITS_MAT_L];
+            int wv = 0;
+            for (int i = lo; i < lo + cnt; ++i) wv = std::max(wv, Lp[i + 1] - Lp[i]);
+            const int64_t nnz_v = (int64_t)Lp[lo + cnt] - Lp[lo];
+            const int64_t n_blk = ((int64_t)cnt + ELL_RB - 1) / ELL_RB;
+            const bool narrow = L.n_off >= 1 && L.n_off <= ELL_MAX_OFF && wv >= 1 && wv <= ELL_MAX_W;
+            const bool wide = !narrow && L.n_off >= 1 && L.n_off <= ELLW_MAX_OFF && wv >= 1 && wv <= ELLW_MAX_W;
+            if (h->sweep_ell_levels && h->D && (narrow || wide) && (lo & 1) == 0 && L.cidx && getenv("ITS_NO_ELL") == nullptr &&
+                n_blk * ELL_RB * wv <= nnz_v + nnz_v / 4 + 8 * ELL_RB) {
+                SweepEll &v = h->level_ell[l];
+                v.w = wv; v.blocks = (int)n_blk; v.kind = narrow ? 1 : 2; v.lo = lo; v.cnt = cnt;
+                const size_t idx_words = narrow ? (size_t)n_blk * ELL_RB : (size_t)n_blk * ELL_RB * ((wv + 3) / 4);
+                if (dalloc(h, &v.val, (size_t)(n_blk * ELL_RB * wv)) || dalloc(h, &v.idx, idx_words)) return ITS_EHIP;
+                CsrDev V;
+                V.n_rows = cnt; V.row_ptr = L.row_ptr + lo; V.col = L.col; V.val = L.val; V.cidx = L.cidx; V.off_dict = L.off_dict;
+                V.n_off = L.n_off; V.ell_w = wv; V.ell_blocks = (int)n_blk; V.ell_kind = v.kind; V.ell_val = v.val; V.ell_idx = v.idx;
+                launch_ell_build(V, h->stream, lo);
+                HIPCHK(h, hipGetLastError());
+            }
+        }
         build_stream_plan(cnt, Lp + lo, blk);              // row indices relative to lo
         h->level_desc_first[l] = (int)desc.size();
         const int nbl = h->level_desc_count[l] = (int)blk.size() - 1;
@@ -747,6 +783,8 @@ static int sweep(its_handle *h, double *x, const double *rhs)
         if (h->level_empty_lo[l] >= 0 && h->sweep_stream) {
             const int lo = h->level_empty_lo[l];
             launch_sweep_empty(x + lo, rhs + lo, h->D + lo, cnt, h->stream);
+        } else if (h->level_ell[l].val && h->sweep_ell_levels && h->sweep_stream) {
+            launch_sweep_ell_view(L, h->level_ell[l], x, rhs, h->D, h->stream);
         } else if (h->level_desc_count[l] > 0 && h->sweep_stream) {
             SpmvArgs a; a.x = x; a.y = x; a.b = rhs; a.D = h->D;   // rows of a level never read each other's x
             launch_spmv_exact_desc(L, h->sweep_desc + h->level_desc_first[l], h->level_desc_count[l], a, EPI_SWEEP, 0, h->stream);

@@ -27,6 +27,7 @@
 namespace its {
 
 typedef double ell_v2d __attribute__((ext_vector_type(2)));
+constexpr int ELL_NONE = -2147483647 - 1;       // column of an empty slot of the byte-index form
 
 template <int W, int EPI, bool DOT>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_ell_kernel(
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ell_kernel(
         if (EPI == EPI_STORE && DOT) ELL_LD2(e0, a.dotv);
         if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) ELL_LD2(e0, a.b);
         if (EPI == EPI_JACOBI_SHIPPED) { ELL_LD2(e0, a.D); ELL_LD2(e1, a.x); ELL_LD2(e2, a.b); }
+        if (EPI == EPI_SWEEP) { ELL_LD2(e0, a.b); ELL_LD2(e1, a.D); }
 #undef ELL_LD2
         int c[W][2];
 #pragma unroll
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ellw_kernel(
         if (EPI == EPI_STORE && DOT) ELL_LD2(e0, a.dotv);
         if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) ELL_LD2(e0, a.b);
         if (EPI == EPI_JACOBI_SHIPPED) { ELL_LD2(e0, a.D); ELL_LD2(e1, a.x); ELL_LD2(e2, a.b); }
+        if (EPI == EPI_SWEEP) { ELL_LD2(e0, a.b); ELL_LD2(e1, a.D); }
 #undef ELL_LD2
         double acc[2] = {0.0, 0.0}, acc2[2] = {0.0, 0.0}, diag[2] = {0.0, 0.0};
 #pragma unroll
@@ -199,18 +202,18 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ellw_kernel(
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const uint32_t by = (iw[2 * bt + (u >> 2)][r] >> (8 * (u & 3))) & 255u;
-                    c[u][r] = by == 255u ? -1 : row0 + r + s_dict[by];
+                    c[u][r] = by == 255u ? ELL_NONE : row0 + r + s_dict[by];     // (a sweep view's columns may be negative: x is shifted)
                 }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) xv[u][r] = a.x[c[u][r] < 0 ? 0 : c[u][r]];
+                for (int r = 0; r < 2; ++r) xv[u][r] = a.x[c[u][r] == ELL_NONE ? 0 : c[u][r]];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (c[u][r] >= 0) chain_step<EPI>(c[u][r], row0 + r, v[u][r], xv[u][r], acc[r], acc2[r], diag[r]);
+                    if (c[u][r] != ELL_NONE) chain_step<EPI>(c[u][r], row0 + r, v[u][r], xv[u][r], acc[r], acc2[r], diag[r]);
         }
         double outv[2] = {0.0, 0.0};
         if (any) outv[0] = row_finish<EPI, DOT>(acc[0], acc2[0], diag[0], e0[0], e1[0], e2[0], lane_sum, lane_max);
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void ellw_build_kernel(
 // ELL image from the device-resident CRS arrays: one lane per (padded) row
 __global__ __launch_bounds__(ITS_BLOCK) void ell_build_kernel(
     int n_rows, int n_pad, int W, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
-    const int *__restrict__ dict, int n_off, double *__restrict__ ell_val, uint32_t *__restrict__ ell_idx)
+    const int *__restrict__ dict, int n_off, double *__restrict__ ell_val, uint32_t *__restrict__ ell_idx, int row_base)
 {
     __shared__ int s_dict[16];
     if (threadIdx.x < 16) s_dict[threadIdx.x] = threadIdx.x < n_off ? dict[threadIdx.x] : 0;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void ell_build_kernel(
         double v = 0.0;
         if (k < len) {
             v = val[j0 + k];
-            const int off = col[j0 + k] - row;
+            const int off = col[j0 + k] - (row + row_base);      // row_base: first row of a view of a larger matrix
             uint32_t d = 0;
             while (d + 1 < (uint32_t)n_off && s_dict[d] != off) ++d;
             wd = (wd & ~(15u << (4 * k))) | (d << (4 * k));
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void ell_build_kernel(
     ell_idx[row] = wd;
 }
 
-void launch_ell_build(const CsrDev &A, hipStream_t s)
+void launch_ell_build(const CsrDev &A, hipStream_t s, int row_base)
 {
     const int n_pad = A.ell_blocks * ELL_RB;
     if (A.ell_kind == 2) {
@@ -298,7 +301,7 @@ void launch_ell_build(const CsrDev &A, hipStream_t s)
         return;
     }
     hipLaunchKernelGGL(ell_build_kernel, dim3((n_pad + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, s, A.n_rows, n_pad,
-                       A.ell_w, A.row_ptr, A.col, A.val, A.off_dict, A.n_off, A.ell_val, A.ell_idx);
+                       A.ell_w, A.row_ptr, A.col, A.val, A.off_dict, A.n_off, A.ell_val, A.ell_idx, row_base);
 }
 
 static int ell_env(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -344,6 +347,7 @@ static void launch_ell_w(const CsrDev &A, const SpmvArgs &a, int epi, int grid, 
     case EPI_GS_RHS: ITS_LAUNCHE(EPI_GS_RHS, false); break;
     case EPI_JACOBI_FUSED: ITS_LAUNCHE(EPI_JACOBI_FUSED, false); break;
     case EPI_GS_FUSED: ITS_LAUNCHE(EPI_GS_FUSED, false); break;
+    case EPI_SWEEP: ITS_LAUNCHE(EPI_SWEEP, false); break;
     default: break;
     }
 #undef ITS_LAUNCHE
@@ -363,6 +367,7 @@ static void launch_ellw_nb(const CsrDev &A, const SpmvArgs &a, int epi, int grid
     case EPI_GS_RHS: ITS_LAUNCHW(EPI_GS_RHS, false); break;
     case EPI_JACOBI_FUSED: ITS_LAUNCHW(EPI_JACOBI_FUSED, false); break;
     case EPI_GS_FUSED: ITS_LAUNCHW(EPI_GS_FUSED, false); break;
+    case EPI_SWEEP: ITS_LAUNCHW(EPI_SWEEP, false); break;
     default: break;
     }
 #undef ITS_LAUNCHW
@@ -400,6 +405,18 @@ void launch_spmv_ell(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t
     case 7: launch_ell_w<7>(A, a, epi, grid, pb, nt, s); break;
     default: launch_ell_w<8>(A, a, epi, grid, pb, nt, s); break;
     }
+}
+
+// One contiguous level (a colour of a multicolour ordering) of crs_L swept on its own ELL image: rows [lo, lo + cnt) of L
+// as a matrix of their own whose vectors are the level's slices of x, rhs and D.  Column offsets are those of L, so the
+// gathers go through x + lo (columns relative to the view may be negative: everything a level reads lies before it).
+void launch_sweep_ell_view(const CsrDev &L, const SweepEll &v, double *x, const double *rhs, const double *D, hipStream_t s)
+{
+    CsrDev V;
+    V.n_rows = v.cnt; V.n_cols = L.n_cols; V.off_dict = L.off_dict; V.n_off = L.n_off;
+    V.ell_val = v.val; V.ell_idx = v.idx; V.ell_w = v.w; V.ell_blocks = v.blocks; V.ell_kind = v.kind; V.ell_pb = 0;
+    SpmvArgs a; a.x = x + v.lo; a.y = x + v.lo; a.b = rhs + v.lo; a.D = D + v.lo;
+    launch_spmv_ell(V, a, EPI_SWEEP, s);
 }
 
 }  // namespace its

@@ -84,6 +84,8 @@ struct its_handle {
     // the exact stream kernels (EPI_SWEEP) over their own row-block descriptors of L
     int4 *sweep_desc = nullptr;                  // device, all such levels back to back
     std::vector<int> level_desc_first, level_desc_count;   // per level; count 0 = level-list kernel
+    std::vector<SweepEll> level_ell;             // per level: its own ELL image (val == nullptr: none), option "sweep_ell_levels"
+    int sweep_ell_levels = 1;
     std::vector<int> level_empty_lo;             // per level: first row of a contiguous level whose rows have no entries in L (-1: not such a level)
     int sweep_stream = 1;                        // option "sweep_stream": 0 = level-list kernel for every level
     // host image of crs_L's row structure, kept at upload so that the schedule needs no copy back from the device:

@@ -139,11 +139,14 @@ const char *spmv_exact_kernel_name(const CsrDev &A, const SpmvArgs &a, int epilo
 // sliced-ELL form of the exact SpMV (its_ell.hip): whole-matrix launches of eligible matrices
 bool spmv_valdict_selected(const CsrDev &A);            // option "spmv_valdict" applies to this matrix
 bool spmv_ell_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);
+// ELL image of one contiguous sweep level of crs_L (its_api.hip build_levels, its_ell.hip launch_sweep_ell_view)
+struct SweepEll { double *val = nullptr; uint32_t *idx = nullptr; int w = 0, blocks = 0, kind = 0, lo = 0, cnt = 0; };
+void launch_sweep_ell_view(const CsrDev &L, const SweepEll &v, double *x, const double *rhs, const double *D, hipStream_t s);
 bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);     // its_panel.hip
 void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 int panel_tune(const char *name, int value);             // "spmv_panel", "spmv_panel_min_cols", "spmv_panel_log2pw", "spmv_panel_grid"
 void launch_spmv_ell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
-void launch_ell_build(const CsrDev &A, hipStream_t s);   // fills ell_val / ell_idx from the device CRS arrays
+void launch_ell_build(const CsrDev &A, hipStream_t s, int row_base = 0);   // fills ell_val / ell_idx from the device CRS arrays
 int ell_tune(const char *name, int value);               // "spmv_ell", "spmv_ell_grid", "spmv_ell_nt", "spmv_ell_map"
 void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);

@@ -243,6 +243,38 @@ def test_multicolor_sweep_on_stream_kernels_is_bit_identical(gen):
     assert ref["r0_two"] > 1.0
 
 
+@pytest.mark.parametrize("gen", ["lap3d_32", "lap2d_200", "cd27_40"])
+def test_multicolor_sweep_on_level_ell_images_is_bit_identical(gen):
+    """A colour of a stencil in multicolour order is swept from an ELL image of its own rows of L (nibble indices for the
+    5-/7-point colours, byte indices for the 27-point ones); option sweep_ell_levels = 0 keeps the CRS stream kernels.
+    Identical histories and iterate, and the iterate equals the oracle's natural-order sweep of the permuted matrix."""
+    from iterative_solvers_amd import matgen
+    rp, col, val = {"lap3d_32": lambda: matgen.laplace3d_7pt(32), "lap2d_200": lambda: matgen.laplace2d_5pt(200),
+                    "cd27_40": lambda: matgen.convdiff3d_27pt(40)}[gen]()
+    n = len(rp) - 1
+    b = np.ones(n)
+    out = []
+    for lev in (1, 0):
+        args = S.Args("gauss-seidel", S.LoopParams(max_iters=25, tol=0.0), S.Flags(), "", "none")
+        sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_MULTICOLOR)
+        try:
+            sol.handle.set_option("sweep_ell_levels", lev)
+            S.preprocessing_crs(args, sol, rp, col, val, b, np.zeros(n))
+            S.solve(args, sol)
+            out.append((args.normed_residuals[:args.loop_params.residual_count].copy(), sol.x_star.copy(), sol.perm.copy()))
+        finally:
+            sol.handle.close()
+    assert len(out[0][0]) > 3
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    orc.set_threads(1)
+    perm = out[0][2]
+    rpp, cp, vp = capi.permute_crs(rp, col, val, perm)
+    ref = orc.solve(rpp, cp, vp, b, np.zeros(n), orc.GAUSS_SEIDEL, max_iters=25, tol=0.0)
+    x_ref = np.empty(n); x_ref[perm] = ref["x_star"]
+    assert np.array_equal(out[0][1], x_ref)
+
+
 def test_gs_fusion_is_refused_for_a_foreign_crs_U():
     """The one-pass GS trip takes its b - U x from A's entries right of the diagonal, which is only the same
     thing if crs_U is that part of A: count, column sum and value hash are compared, and a crs_U that differs

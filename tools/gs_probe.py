@@ -7,11 +7,13 @@ sys.path.insert(0, ROOT)
 from iterative_solvers_amd import capi, matgen, solver as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 order = capi.GS_MULTICOLOR if (len(sys.argv) < 3 or sys.argv[2] == "mc") else capi.GS_LEVEL
-rp, col, val = matgen.laplace3d_7pt(int(os.environ["LAP"])) if os.environ.get("LAP") else matgen.powerlaw(n)
+rp, col, val = (matgen.laplace3d_7pt(int(os.environ["LAP"])) if os.environ.get("LAP") else
+                matgen.convdiff3d_27pt(int(os.environ["CD27"])) if os.environ.get("CD27") else matgen.powerlaw(n))
 n = len(rp) - 1
 args = S.Args("gauss-seidel", S.LoopParams(max_iters=10**9, tol=0.0))
 sol = S.Solver("gauss-seidel", device=0, gs_order=order)
 sol.handle.set_option("fused_residual", int(os.environ.get("FUSED", "1")))
+sol.handle.set_option("sweep_ell_levels", int(os.environ.get("LEVELL", "1")))
 S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
 h = sol.handle
 for it in range(2): h.iterate(it)
