@@ -93,6 +93,13 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *   "gmres_ortho"  0 (default) = modified Gram-Schmidt (methods/gmres.hpp:269-329), one reduction per basis vector;
  *                  1 = classical Gram-Schmidt applied twice (CGS-2) with batched dot products: 3 reductions per trip
  *                  whatever the inner index.  Same standing as cg_variant 1.
+ *   "gmres_persist" 1 (default) = the Gram-Schmidt sweep of a GMRES trip (gmres.hpp:269-389: every h_j = w . v_j,
+ *                  w -= h_j v_j, ||w||, v_{k+1}) is ONE persistent launch that keeps w in registers and reads each
+ *                  basis vector once (its_mgs.hip), when the run is on one GPU, uses modified Gram-Schmidt and the
+ *                  vectors have between "gmres_persist_min_n" (default 2^19) and 12 * 960 * CUs (2.9 M) entries;
+ *                  0 = one launch per basis vector.  Same operations per element; the dot products are summed in
+ *                  another fixed order (H agrees to rounding, not bit for bit).  A launch whose workgroups cannot all
+ *                  be resident (another process on the GPU) gives up after 20 ms and the trip is repeated the other way.
  *   "fused_residual" 1 (default) = a Jacobi / Gauss-Seidel trip reads A once: the pass that records
  *                  ||b - A x_new|| (utility_funcs.hpp:423-447) also produces the next trip's product of
  *                  x_new (second in-order chain per row); 0 = separate launches.  Same bits either way.
@@ -194,6 +201,9 @@ int its_spmv_kernel_info(its_handle *h, int which, int with_dot, char *name, int
 /* plan facts: lanes per row chosen, SELL occupancy (nnz / stored elements), row-block count */
 int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occupancy,
                   int *n_row_blocks);
+/* after its_solver_setup(ITS_GMRES): workgroups of the persistent Gram-Schmidt launch ("gmres_persist"; 0 = the trips
+ * run one launch per basis vector) and how many trips had to be repeated that way because the launch gave up */
+int its_gmres_info(its_handle *h, int *persist_grid, int *fallbacks);
 
 /* ---- Gauss-Seidel ordering helpers (host only, no GPU needed) -------------------------
  * methods/gauss_seidel.hpp sweeps in natural order; its_solver_setup schedules that sweep by

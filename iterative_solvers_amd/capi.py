@@ -63,6 +63,7 @@ SIGNATURES = {
     "its_last_spmv_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "its_spmv_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, _c_i64_p]),
     "its_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_int_p, _c_dbl_p, _c_int_p]),
+    "its_gmres_info": (C.c_int, [C.c_void_p, _c_int_p, _c_int_p]),
     "its_extract_diag": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "its_split_lu": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
     "its_multicolor_order": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _c_int_p]),
@@ -276,6 +277,11 @@ class Handle:
         lpr, occ, nb = C.c_int(), C.c_double(), C.c_int()
         self.check(self.L.its_plan_info(self.h, which, fmt, C.byref(lpr), C.byref(occ), C.byref(nb)), "its_plan_info")
         return {"lanes_per_row": lpr.value, "sell_occupancy": occ.value, "n_row_blocks": nb.value}
+
+    def gmres_info(self):
+        g, f = C.c_int(), C.c_int()
+        self.check(self.L.its_gmres_info(self.h, C.byref(g), C.byref(f)), "its_gmres_info")
+        return {"persist_grid": g.value, "fallbacks": f.value}
 
     # ---- device memory
     def dev_alloc(self, nbytes: int) -> int:

@@ -127,7 +127,7 @@ extern "C" int its_destroy(its_handle *h)
     for (auto &A : h->mat) free_csr(A);
     dfree(h->D); dfree(h->b); dfree(h->r); dfree(h->tmp); dfree(h->x_a); dfree(h->x_b); dfree(h->x);
     dfree(h->p); dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
-    dfree(h->pcg_w); dfree(h->pcg_s); dfree(h->pcg_z); dfree(h->pcg_pair[0]); dfree(h->pcg_pair[1]); dfree(h->gram_part); dfree(h->gram_h);
+    dfree(h->pcg_w); dfree(h->pcg_s); dfree(h->pcg_z); dfree(h->pcg_pair[0]); dfree(h->pcg_pair[1]); dfree(h->gram_part); dfree(h->gram_h); dfree(h->mgs_slots);
     for (auto &e : h->prof_ev) (void)hipEventDestroy(e);
     for (auto &p : h->part) dfree(p);
     dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows); dfree(h->sweep_desc); free_level_ell(h);
@@ -474,6 +474,18 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->gmres_ortho = value;
         return ITS_OK;
     }
+    if (!strcmp(name, "gmres_persist")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "gmres_persist: 0 (one launch per basis vector) or 1 (one persistent launch per trip)");
+        if (h->setup_done && h->solver == ITS_GMRES) FAIL(h, ITS_ESTATE, "set gmres_persist before its_solver_setup");
+        h->gmres_persist = value;
+        return ITS_OK;
+    }
+    if (!strcmp(name, "gmres_persist_min_n")) {
+        if (value < 1) FAIL(h, ITS_EINVAL, "gmres_persist_min_n >= 1");
+        if (h->setup_done && h->solver == ITS_GMRES) FAIL(h, ITS_ESTATE, "set gmres_persist_min_n before its_solver_setup");
+        h->gmres_persist_min_n = value;
+        return ITS_OK;
+    }
     if (!strcmp(name, "readback")) {
         if (value < 0 || value > 2) FAIL(h, ITS_EINVAL, "readback: 0 (watch the pinned word), 1 (synchronize), 2 (copy + synchronize)");
         g_readback_mode = value;
@@ -518,6 +530,14 @@ extern "C" int its_plan_info(its_handle *h, int which, int format, int *lanes_pe
     if (lanes_per_row) *lanes_per_row = A.lanes_per_row;
     if (sell_occ) *sell_occ = A.sell_elems ? (double)A.nnz / (double)A.sell_elems : 0.0;
     if (n_row_blocks) *n_row_blocks = A.n_blocks;
+    return ITS_OK;
+}
+
+extern "C" int its_gmres_info(its_handle *h, int *persist_grid, int *fallbacks)
+{
+    if (!h) return ITS_EINVAL;
+    if (persist_grid) *persist_grid = h->mgs_grid;
+    if (fallbacks) *fallbacks = h->mgs_fallbacks;
     return ITS_OK;
 }
 
@@ -889,6 +909,12 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
             dfree(h->gram_part); dfree(h->gram_h);
             if (dalloc(h, &h->gram_part, (size_t)(m + 2) * gram_blocks()) || dalloc(h, &h->gram_h, (size_t)2 * (m + 2))) return ITS_EHIP;
         }
+        // persistent Gram-Schmidt launch (its_mgs.hip): one GPU, modified Gram-Schmidt, vectors that fit one resident grid
+        dfree(h->mgs_slots); h->mgs_grid = 0; h->mgs_fallbacks = 0;
+        if (h->gmres_persist && h->gmres_ortho == 0 && !its_dist_active(h) && n >= h->gmres_persist_min_n) {
+            h->mgs_grid = mgs_persist_grid(n, h->device);
+            if (h->mgs_grid > 0 && dalloc(h, &h->mgs_slots, mgs_persist_slot_words(m, h->mgs_grid))) return ITS_EHIP;
+        }
         h->restart_count = 0;
         // beta = ||r||, V[0] = r * (1/beta)   (gmres.hpp:734-736,768-771)
         launch_dot_partials(h->r, h->r, n, h->part[0], h->stream);
@@ -1081,8 +1107,26 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     // — DESIGN.md §4 — but the assumption is not needed.)
     static const bool arm_last_only = getenv("ITS_GMRES_ARM_LAST_ONLY") != nullptr;     // the old protocol, for A/B runs of tools/repeat_cli.sh
     if (hcol_pinned) for (int i = arm_last_only ? k + 1 : 0; i <= k + 1; ++i) arm_pinned_word(hcol_out + i);
+    // the whole sweep as one persistent launch with w in registers (its_mgs.hip) when the set-up found it applicable;
+    // w in memory is not modified by it, so a launch that gave up (grid not co-resident) is repeated by the per-step kernels
+    bool persist = h->mgs_grid > 0 && hcol_pinned;
+    if (persist) {
+        HIPCHK(h, launch_mgs_persist(w, h->V, (int64_t)ld, k + 1, h->V + (size_t)(k + 1) * ld, hcol_out, h->mgs_slots, m, h->mgs_grid, n, h->stream));
+        if ((rc = wait_pinned_word(h, hcol_out + (k + 1)))) return rc;
+        if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + (k + 1)) == kPendingWord) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + (k + 1)) == kPendingWord) {
+                persist = false;
+                if (h->watch_misses > 0) --h->watch_misses;            // the window that ran out was this launch's, not a slow trip's
+                if (++h->mgs_fallbacks >= 2) h->mgs_grid = 0;          // twice: this handle stays on the per-step kernels
+                for (int i = 0; i <= k + 1; ++i) arm_pinned_word(hcol_out + i);
+            }
+        }
+    }
     const double *prev_part = nullptr; int prev_scalar = 0;
-    if (h->gmres_ortho == 1) {
+    if (persist) {
+        // everything below already happened inside the launch
+    } else if (h->gmres_ortho == 1) {
         // CGS-2 ("gmres_ortho" 1): h1 = V^T w, w -= V h1, h2 = V^T w, w -= V h2, H[:,k] = h1 + h2 — every product
         // batched over j, one reduction per pass and one for ||w||: 3 per trip instead of k + 2
         const int nv = k + 1;
@@ -1109,7 +1153,7 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
         if ((rc = allreduce_partials(h, next_part, 0))) return rc;
     }
     // H[k+1,k] = ||w||, V[k+1] = w / H[k+1,k]   (gmres.hpp:359,389)
-    launch_mgs_normalize(h->V + (size_t)(k + 1) * ld, w, prev_part, prev_scalar, hcol_out + (k + 1), n, h->stream);
+    if (!persist) launch_mgs_normalize(h->V + (size_t)(k + 1) * ld, w, prev_part, prev_scalar, hcol_out + (k + 1), n, h->stream);
     HIPCHK(h, hipGetLastError());
     double *hc = h->hcol.data();
     if (hcol_pinned) {

@@ -48,6 +48,11 @@ struct its_handle {
     int gmres_givens = 0;                 // 0: O(m) rotation updates, 1: the reference's dense products
     // communication-reducing variants (its_krylov_cr.hip), opt-in: "cg_variant" 1 = pipelined CG, "gmres_ortho" 1 = CGS-2
     int cg_variant = 0, gmres_ortho = 0;
+    // persistent modified Gram-Schmidt (its_mgs.hip): option "gmres_persist" (1), for vectors of at least
+    // "gmres_persist_min_n" doubles that fit the registers of one resident grid; mgs_grid == 0: per-step kernels
+    int gmres_persist = 1, gmres_persist_min_n = 1 << 19;
+    unsigned long long *mgs_slots = nullptr;
+    int mgs_grid = 0, mgs_fallbacks = 0;
     double *pcg_w = nullptr, *pcg_s = nullptr, *pcg_z = nullptr;     // pipelined CG: w = A r, s = A p, z = A s
     double *pcg_pair[2] = {nullptr, nullptr};                        // (r,r) and (w,r) partials, double-buffered by trip parity
     int pcg_trip = 0;

@@ -190,6 +190,12 @@ void launch_mgs_step(double *w, const double *v_prev, const double *part_prev, i
 // v_out = w * (1/sqrt(sum part_ww)) ; block 0 stores sqrt(sum) to h_out[0]
 void launch_mgs_normalize(double *v_out, const double *w, const double *part_ww, int ww_is_scalar,
                           double *h_out, int64_t n, hipStream_t s);
+// The whole sweep — every step, ||w|| and v_{k+1} = w / ||w|| — as one persistent launch with w in registers
+// (its_mgs.hip).  mgs_persist_grid: workgroups it would use for vectors of n doubles on this device, 0 = not applicable.
+int mgs_persist_grid(int64_t n, int device);
+size_t mgs_persist_slot_words(int m, int G);
+hipError_t launch_mgs_persist(const double *w_in, const double *V, int64_t ld, int nv, double *v_out, double *h_out,
+                              unsigned long long *slots, int m, int G, int64_t n, hipStream_t s);
 // x = x0 + sum_{k<m} y[k] * V[k*ldv + i], in order k = 0..m-1 (gmres.hpp:940,971-972)
 void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t ldv,
                            const double *y_dev, int m, int64_t n, hipStream_t s);

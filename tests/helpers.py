@@ -23,6 +23,7 @@ def random_crs(n, max_len, seed, n_cols=None, empty_every=0, long_rows=()):
 
 MATRICES = {
     "lap2d_16": lambda: matgen.laplace2d_5pt(16),
+    "lap2d_33": lambda: matgen.laplace2d_5pt(33),          # odd number of rows
     "lap2d_64": lambda: matgen.laplace2d_5pt(64),
     "lap3d_8": lambda: matgen.laplace3d_7pt(8),
     "lap3d_16": lambda: matgen.laplace3d_7pt(16),

@@ -126,11 +126,13 @@ def test_gmres50_27pt_128cubed_history():
     try:
         S.preprocessing_crs(args, sol, rp, col, val, b, b.copy())
         assert sol.handle.spmv_kernel_info(capi.MAT_A)[0] == "spmv_ellw_kernel"
+        assert sol.handle.gmres_info()["persist_grid"] > 0           # the persistent Gram-Schmidt launch (its_mgs.hip)
         got = []
         for it in range(trips):
             got.append(sol.handle.iterate(it))
             if (it + 1) % 50 == 0:
                 sol.restart_gmres(it)
+        assert sol.handle.gmres_info()["fallbacks"] == 0
     finally:
         sol.handle.close()
     # (the oracle's own 1-vs-8-thread histories differ by 1e-11 at trip 0 and 1e-9 by trip 10 here: 2 M-term

@@ -40,7 +40,7 @@ KIND = {"-j": orc.JACOBI, "-gs": orc.GAUSS_SEIDEL, "-cg": orc.CG, "-gm": orc.GMR
 
 
 def run_both(name, flag, scale="none", precond="", max_iters=400, restart=100, jacobi_mode=0, tol=1e-10,
-             fmt=capi.FMT_CSR_EXACT):
+             fmt=capi.FMT_CSR_EXACT, options=None, info=None):
     orc.set_threads(1)
     rp, col, val = MATRICES[name]()
     n = len(rp) - 1
@@ -56,9 +56,13 @@ def run_both(name, flag, scale="none", precond="", max_iters=400, restart=100, j
                   {"": "", "gs": "gauss-seidel"}[precond], scale)
     sol = S.Solver(args.solver_type, args.preconditioner_type, device=0, spmv_format=fmt, jacobi_mode=jacobi_mode)
     try:
+        for key, value in (options or {}).items():
+            sol.handle.set_option(key, value)
         S.preprocessing(args, sol, n, rows.astype(np.int64), col.astype(np.int64), val.copy())
         S.solve(args, sol)
         xs = sol.x_star.copy()
+        if info is not None and flag == "-gm":
+            info.update(sol.handle.gmres_info())
     finally:
         sol.handle.close()
     return ref, args, xs
