@@ -480,6 +480,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->gmres_persist = value;
         return ITS_OK;
     }
+    if (!strcmp(name, "gmres_persist_inject_fail")) {       // tests of the fallback: that many launches give up on purpose
+        if (value < 0) FAIL(h, ITS_EINVAL, "gmres_persist_inject_fail >= 0");
+        h->mgs_inject_fail = value;
+        return ITS_OK;
+    }
     if (!strcmp(name, "gmres_persist_min_n")) {
         if (value < 1) FAIL(h, ITS_EINVAL, "gmres_persist_min_n >= 1");
         if (h->setup_done && h->solver == ITS_GMRES) FAIL(h, ITS_ESTATE, "set gmres_persist_min_n before its_solver_setup");
@@ -914,6 +919,7 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         if (h->gmres_persist && h->gmres_ortho == 0 && !its_dist_active(h) && n >= h->gmres_persist_min_n) {
             h->mgs_grid = mgs_persist_grid(n, h->device);
             if (h->mgs_grid > 0 && dalloc(h, &h->mgs_slots, mgs_persist_slot_words(m, h->mgs_grid))) return ITS_EHIP;
+            if (h->mgs_grid > 0) HIPCHK(h, mgs_persist_reset(h->mgs_slots, m, h->mgs_grid, h->stream));
         }
         h->restart_count = 0;
         // beta = ||r||, V[0] = r * (1/beta)   (gmres.hpp:734-736,768-771)
@@ -1111,12 +1117,14 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     // w in memory is not modified by it, so a launch that gave up (grid not co-resident) is repeated by the per-step kernels
     bool persist = h->mgs_grid > 0 && hcol_pinned;
     if (persist) {
-        HIPCHK(h, launch_mgs_persist(w, h->V, (int64_t)ld, k + 1, h->V + (size_t)(k + 1) * ld, hcol_out, h->mgs_slots, m, h->mgs_grid, n, h->stream));
+        HIPCHK(h, launch_mgs_persist(w, h->V, (int64_t)ld, k + 1, h->V + (size_t)(k + 1) * ld, hcol_out, h->mgs_slots, h->mgs_parity++, m, h->mgs_grid, n, h->stream,
+                                     h->mgs_inject_fail > 0 ? h->mgs_inject_fail-- : 0));
         if ((rc = wait_pinned_word(h, hcol_out + (k + 1)))) return rc;
         if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + (k + 1)) == kPendingWord) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
             if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + (k + 1)) == kPendingWord) {
                 persist = false;
+                HIPCHK(h, mgs_persist_reset(h->mgs_slots, m, h->mgs_grid, h->stream));
                 if (h->watch_misses > 0) --h->watch_misses;            // the window that ran out was this launch's, not a slow trip's
                 if (++h->mgs_fallbacks >= 2) h->mgs_grid = 0;          // twice: this handle stays on the per-step kernels
                 for (int i = 0; i <= k + 1; ++i) arm_pinned_word(hcol_out + i);

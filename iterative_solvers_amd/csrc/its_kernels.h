@@ -195,7 +195,8 @@ void launch_mgs_normalize(double *v_out, const double *w, const double *part_ww,
 int mgs_persist_grid(int64_t n, int device);
 size_t mgs_persist_slot_words(int m, int G);
 hipError_t launch_mgs_persist(const double *w_in, const double *V, int64_t ld, int nv, double *v_out, double *h_out,
-                              unsigned long long *slots, int m, int G, int64_t n, hipStream_t s);
+                              unsigned long long *slots, int parity, int m, int G, int64_t n, hipStream_t s, int inject_fail = 0);
+hipError_t mgs_persist_reset(unsigned long long *slots, int m, int G, hipStream_t s);
 // x = x0 + sum_{k<m} y[k] * V[k*ldv + i], in order k = 0..m-1 (gmres.hpp:940,971-972)
 void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t ldv,
                            const double *y_dev, int m, int64_t n, hipStream_t s);

@@ -7,7 +7,8 @@
 // across the steps a step reads 8 n bytes.
 // How.  One workgroup per CU (15 data waves + 1 polling wave), every data lane owns EP pairs of elements of w for the
 // whole launch.  Step j: partial sums of w . v_j -> one 8-byte SLOT per workgroup and step, preset to a sentinel
-// (all ones) by a memset queued before the launch; the polling wave of workgroup 0 gathers the G slots in a fixed order
+// (all ones: there are two sets of slots, a launch uses one and presets the other for the launch after it — a memset
+// per trip cost 4.8 us); the polling wave of workgroup 0 gathers the G slots in a fixed order
 // and publishes h_j in MGS_NB copies (watched by 1 / MGS_NB of the other workgroups' polling waves each: 256 pollers on
 // one word cost 0.5 us of the 3.7).  Data and arrival flag
 // are the same word, stores and loads are agent-scope relaxed atomics (write-through / L2 bypass): no fence, no counter.
@@ -48,7 +49,8 @@ __device__ __forceinline__ void mgs_publish(unsigned long long *slot, double v)
 template <int EP>
 __global__ __launch_bounds__(MGS_NT + 64) void mgs_persist_kernel(
     const double *__restrict__ w_in, const double *__restrict__ V, int64_t ld, int nv,
-    double *__restrict__ v_out, double *__restrict__ h_out, unsigned long long *slots, int bst, int64_t n)
+    double *__restrict__ v_out, double *__restrict__ h_out, unsigned long long *slots, unsigned long long *__restrict__ arm,
+    int rows, int bst, int64_t n, int inject_fail)
 {
     __shared__ double s_red[MGS_NWD];
     __shared__ double s_h;
@@ -67,6 +69,12 @@ __global__ __launch_bounds__(MGS_NT + 64) void mgs_persist_kernel(
     };
     double2 w[EP], vc[EP], vn[EP];
     if (t == 0) s_fail = 0;
+    if (poller) {
+        // preset the OTHER set of slots for the next launch (nobody reads it during this one; the kernel boundary
+        // makes the stores visible): this workgroup's slot of every step, workgroup 0 also the published copies
+        for (int r = lane; r < rows; r += 64) arm[(size_t)MGS_NB * bst + (size_t)r * G + blockIdx.x] = MGS_SENT;
+        if (blockIdx.x == 0) for (int i = lane; i < MGS_NB * bst; i += 64) arm[i] = MGS_SENT;
+    }
 #pragma unroll
     for (int u = 0; u < EP; ++u) { w[u] = ld2(w_in, g + u * stride); vn[u] = nv > 0 ? ld2(V, g + u * stride) : make_double2(0.0, 0.0); }
     for (int j = 0; j <= nv; ++j) {
@@ -98,7 +106,9 @@ __global__ __launch_bounds__(MGS_NT + 64) void mgs_persist_kernel(
             }
             double acc = 0.0; bool fail = false;
             const long long t0 = wall_clock64();
-            if (blockIdx.x == 0) {
+            if (blockIdx.x == 0 && inject_fail) {
+                fail = true;                                     // test hook: workgroup 0 never publishes, the others run into their time limit
+            } else if (blockIdx.x == 0) {
                 // all of a lane's slots are asked for at once; only those still pending are asked for again
                 unsigned long long b[MGS_KQ];
 #pragma unroll
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(MGS_NT + 64) void mgs_persist_kernel(
     }
 }
 
-typedef void (*mgs_kernel_t)(const double *, const double *, int64_t, int, double *, double *, unsigned long long *, int, int64_t);
+typedef void (*mgs_kernel_t)(const double *, const double *, int64_t, int, double *, double *, unsigned long long *, unsigned long long *, int, int, int64_t, int);
 static mgs_kernel_t mgs_kernel_for(int ep)
 {
     switch (ep) {
@@ -176,20 +186,24 @@ int mgs_persist_grid(int64_t n, int device)
     return G;
 }
 static int mgs_bst(int m) { return (m + 2 + 31) & ~31; }
-size_t mgs_persist_slot_words(int m, int G) { return (size_t)MGS_NB * mgs_bst(m) + (size_t)(m + 2) * (size_t)G; }
+static size_t mgs_set_words(int m, int G) { return (size_t)MGS_NB * mgs_bst(m) + (size_t)(m + 2) * (size_t)G; }
+size_t mgs_persist_slot_words(int m, int G) { return 2 * mgs_set_words(m, G); }
+// both sets to the sentinel: at set-up and after a launch that gave up
+hipError_t mgs_persist_reset(unsigned long long *slots, int m, int G, hipStream_t s)
+{ return hipMemsetAsync(slots, 0xFF, mgs_persist_slot_words(m, G) * sizeof(unsigned long long), s); }
 
 // w_in: A v_k (not modified).  V: basis, nv = k + 1 vectors of leading dimension ld.  v_out: V[k+1].  h_out: nv + 1 words
-// (the Hessenberg column).  slots: mgs_persist_slot_words(m, G) words, m (the restart length) >= nv.
+// (the Hessenberg column).  slots: mgs_persist_slot_words(m, G) words, all ones before the first launch
+// (mgs_persist_reset); m (the restart length) >= nv; parity: 0 / 1, alternating from launch to launch.
 hipError_t launch_mgs_persist(const double *w_in, const double *V, int64_t ld, int nv, double *v_out, double *h_out,
-                              unsigned long long *slots, int m, int G, int64_t n, hipStream_t s)
+                              unsigned long long *slots, int parity, int m, int G, int64_t n, hipStream_t s, int inject_fail)
 {
     mgs_kernel_t k = mgs_kernel_for(mgs_ep(n, G));
     if (!k) return hipErrorInvalidValue;
     if (nv > m) return hipErrorInvalidValue;
     const int bst = mgs_bst(m);
-    hipError_t e = hipMemsetAsync(slots, 0xFF, ((size_t)MGS_NB * bst + (size_t)(nv + 1) * (size_t)G) * sizeof(unsigned long long), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(G), dim3(MGS_NT + 64), 0, s, w_in, V, ld, nv, v_out, h_out, slots, bst, n);
+    unsigned long long *use = slots + (parity & 1) * mgs_set_words(m, G), *arm = slots + ((parity & 1) ^ 1) * mgs_set_words(m, G);
+    hipLaunchKernelGGL(k, dim3(G), dim3(MGS_NT + 64), 0, s, w_in, V, ld, nv, v_out, h_out, use, arm, m + 2, bst, n, inject_fail);
     return hipGetLastError();
 }
 
