@@ -73,6 +73,11 @@ def pmc_traffic(kernel_substr):
         if line.startswith("# kernel_sources_sha256="):
             stamp = line.split("=", 1)[1].strip()
         if kernel_substr in line and "avg=" in line:
+            # the instantiation the CG loop launches: plain store epilogue fused with the p.Ap partial sums
+            # (spmv_ell_kernel<W, 0, true>, spmv_stream4_kernel<0, true, V>), not the Jacobi / residual forms
+            targs = line.split(kernel_substr, 1)[1].split(">", 1)[0].replace(" ", "").split(",")
+            if "true" not in targs or "0" not in targs:
+                continue
             kb = float(line.split("avg=")[1].split("KB")[0])
             if line.startswith("FETCH_SIZE"):
                 fetch = kb
