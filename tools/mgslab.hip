@@ -153,8 +153,17 @@ __global__ __launch_bounds__((NWD + 1) * 64) void mgs_persist2_kernel(const doub
             if (lane == 0) s_red[wv] = ws;
         }
         __syncthreads();
-        unsigned long long *sl = slots + (size_t)j * (G + 8);
+        unsigned long long *sl = TWO == 3 ? slots + (size_t)j * NB * G : slots + (size_t)j * (G + 8);
         if (poller) {
+            if (TWO == 3) {
+                double bs = 0.0;
+#pragma unroll
+                for (int q = 0; q < NWD; ++q) bs += s_red[q];
+                unsigned long long bits = __double_as_longlong(bs);
+                if (bits == SENT) bits = 0x7FF8000000000000ull;
+                if (lane < NB) __hip_atomic_store(sl + (size_t)lane * G + blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sl += (size_t)(blockIdx.x % NB) * G;
+            } else
             if (lane == 0) {
                 double bs = 0.0;
 #pragma unroll
@@ -164,7 +173,7 @@ __global__ __launch_bounds__((NWD + 1) * 64) void mgs_persist2_kernel(const doub
                 __hip_atomic_store(sl + blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             double acc = 0.0; bool fail = false;
-            if (!TWO || blockIdx.x == 0 || (TWO == 2 && blockIdx.x < 8)) {
+            if (!TWO || TWO == 3 || blockIdx.x == 0 || (TWO == 2 && blockIdx.x < 8)) {
                 // KQ slots per lane, all loads in flight at once; only the still-pending ones are asked for again
                 unsigned long long b[KQ];
 #pragma unroll
@@ -185,7 +194,8 @@ __global__ __launch_bounds__((NWD + 1) * 64) void mgs_persist2_kernel(const doub
 #pragma unroll
                 for (int u = 0; u < KQ; ++u) if (lane + u * 64 < G) acc += __longlong_as_double(b[u]);
                 acc = wave_sum(acc);
-                if (TWO && NB > 1) {
+                if (TWO == 3) {
+                } else if (TWO && NB > 1) {
                     unsigned long long bits = __double_as_longlong(acc);
                     if (bits == SENT) bits = 0x7FF8000000000000ull;
                     if (lane < NB) __hip_atomic_store(slots + (size_t)64 * (G + 8) + (size_t)lane * BST + j, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -240,7 +250,8 @@ int main(int argc, char **argv)
     for (auto &v : hw) v = rnd();
     double *V, *w, *hout; unsigned long long *slots; int *err;
     CK(hipMalloc(&V, hV.size() * 8)); CK(hipMalloc(&w, n * 8)); CK(hipMalloc(&hout, (nv + 2) * 8));
-    CK(hipMalloc(&slots, ((size_t)64 * 1032 + 64 * 512) * 8)); CK(hipMalloc(&err, 4));
+    const size_t slot_bytes = (size_t)(nv + 1) * 64 * 512 * 8 + ((size_t)64 * 1032 + 64 * 512) * 8;
+    CK(hipMalloc(&slots, slot_bytes)); CK(hipMalloc(&err, 4));
     CK(hipMemcpy(V, hV.data(), hV.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), n * 8, hipMemcpyHostToDevice));
     CK(hipMemset(err, 0, 4));
     // host reference (same MGS, plain double)
@@ -262,7 +273,7 @@ int main(int argc, char **argv)
         double *vout = V + (size_t)nv * ld;
         float best = 1e30f, sum = 0;
         for (int r = 0; r < reps + 3; ++r) {
-            CK(hipMemsetAsync(slots, 0xFF, ((size_t)64 * (G + 8) + 64 * 512) * 8, st));
+            CK(hipMemsetAsync(slots, 0xFF, slot_bytes, st));
             CK(hipEventRecord(e0, st));
             hipLaunchKernelGGL(kern, dim3(G), dim3(NT + extra), 0, st, w, V, ld, nv, vout, hout, slots, err, n);
             CK(hipEventRecord(e1, st));
@@ -284,6 +295,10 @@ int main(int argc, char **argv)
     run(mgs_persist_kernel<512, 4>, 512, 4, cus * 2, "persist<512,4> x2");
     run(mgs_persist2_kernel<15, 5, 0>, 960, 5, cus, "persist2<15,5> all-to-all", 64);
     run(mgs_persist2_kernel<15, 5, 1>, 960, 5, cus, "persist2<15,5> two-level", 64);
+    run(mgs_persist2_kernel<15, 5, 3, 0, 8>, 960, 5, cus, "persist2<15,5> all-to-all r8", 64);
+    run(mgs_persist2_kernel<15, 5, 3, 0, 16>, 960, 5, cus, "persist2<15,5> all-to-all r16", 64);
+    run(mgs_persist2_kernel<15, 5, 3, 0, 32>, 960, 5, cus, "persist2<15,5> all-to-all r32", 64);
+    run(mgs_persist2_kernel<15, 5, 3, 0, 64>, 960, 5, cus, "persist2<15,5> all-to-all r64", 64);
     run(mgs_persist2_kernel<15, 5, 1, 0, 4>, 960, 5, cus, "persist2<15,5> two-level nb4", 64);
     run(mgs_persist2_kernel<15, 5, 1, 0, 8>, 960, 5, cus, "persist2<15,5> two-level nb8", 64);
     run(mgs_persist2_kernel<15, 5, 1, 0, 16>, 960, 5, cus, "persist2<15,5> two-level nb16", 64);
