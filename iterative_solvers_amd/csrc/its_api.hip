@@ -377,13 +377,11 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
             const int64_t stored = n_blk * ELL_RB * A.max_row_len;
             if (stored <= nnz + nnz / 4 + 8 * ELL_RB && stored < ((int64_t)1 << 40)) {
                 A.ell_w = A.max_row_len; A.ell_blocks = (int)n_blk; A.ell_kind = narrow ? 1 : 2;
-                int far = 0;
                 {
                     std::vector<int> dict(256);
                     HIPCHK(h, hipMemcpy(dict.data(), A.off_dict, 256 * sizeof(int), hipMemcpyDeviceToHost));
-                    for (int i = 0; i < A.n_off; ++i) far = std::max(far, std::abs(dict[i]));
+                    A.ell_pb = ell_choose_period(dict.data(), A.n_off);
                 }
-                A.ell_pb = far / ELL_RB >= 8 ? far / ELL_RB : 0;
                 const size_t idx_words = narrow ? (size_t)n_blk * ELL_RB : (size_t)n_blk * ELL_RB * ((A.ell_w + 3) / 4);
                 if (dalloc(h, &A.ell_val, (size_t)stored) || dalloc(h, &A.ell_idx, idx_words)) return ITS_EHIP;
                 launch_ell_build(A, h->stream);
@@ -707,6 +705,7 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
     // keep the level-list kernel.
     h->level_desc_first.assign(nl, 0); h->level_desc_count.assign(nl, 0); h->level_empty_lo.assign(nl, -1);
     free_level_ell(h); h->level_ell.assign(nl, SweepEll());
+    int L_pb = -1;                                           // period of the ELL work map from L's offsets (first use)
     std::vector<int4> desc;
     std::vector<int> blk;
     for (int l = 0; l < nl; ++l) {
@@ -731,7 +730,12 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
             if (h->sweep_ell_levels && h->D && (narrow || wide) && (lo & 1) == 0 && L.cidx && getenv("ITS_NO_ELL") == nullptr &&
                 n_blk * ELL_RB * wv <= nnz_v + nnz_v / 4 + 8 * ELL_RB) {
                 SweepEll &v = h->level_ell[l];
-                v.w = wv; v.blocks = (int)n_blk; v.kind = narrow ? 1 : 2; v.lo = lo; v.cnt = cnt;
+                if (L_pb < 0) {
+                    std::vector<int> dict(256);
+                    HIPCHK(h, hipMemcpy(dict.data(), L.off_dict, 256 * sizeof(int), hipMemcpyDeviceToHost));
+                    L_pb = ell_choose_period(dict.data(), L.n_off);
+                }
+                v.w = wv; v.blocks = (int)n_blk; v.kind = narrow ? 1 : 2; v.lo = lo; v.cnt = cnt; v.pb = L_pb;
                 const size_t idx_words = narrow ? (size_t)n_blk * ELL_RB : (size_t)n_blk * ELL_RB * ((wv + 3) / 4);
                 if (dalloc(h, &v.val, (size_t)(n_blk * ELL_RB * wv)) || dalloc(h, &v.idx, idx_words)) return ITS_EHIP;
                 CsrDev V;

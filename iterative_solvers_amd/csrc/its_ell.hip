@@ -21,8 +21,10 @@
 // over-fetch in the round-1 PMC record).  Otherwise XCD e owns the e-th contiguous eighth of the row blocks.
 #include "its_kernels.h"
 #include "its_epilogue.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace its {
 
@@ -304,6 +306,37 @@ void launch_ell_build(const CsrDev &A, hipStream_t s, int row_base)
                        A.ell_w, A.row_ptr, A.col, A.val, A.off_dict, A.n_off, A.ell_val, A.ell_idx, row_base);
 }
 
+// Period (in row blocks) of the work map for a matrix whose col - row values are `dict`: the P for which (nearly) every
+// offset is close to a multiple of P rows, so that the rows an XCD owns — the same eighth of every period — gather x
+// from what that XCD streams anyway.  Natural-order 3-D stencils: the plane (7-pt 256^3: 128 blocks).  The same stencil
+// in red-black order has offsets n/2 + {0, +-1, +-line/2, +-plane/2}: the largest one says nothing, the period is the
+// half plane (64 blocks; GS trip at 256^3 0.509 -> 0.47 ms).  Candidates are the offsets and their pairwise differences,
+// rounded to whole blocks; a candidate may leave a quarter of the offsets unexplained (the halo columns of a row-block
+// partition); fewest unexplained, then smallest residue, then shortest period wins.  0 = no period (contiguous eighths).
+int ell_choose_period(const int *dict, int n_off)
+{
+    if (n_off < 1) return 0;
+    std::vector<int64_t> mag;
+    for (int i = 0; i < n_off; ++i) mag.push_back(std::llabs((long long)dict[i]));
+    std::vector<int> cand;
+    auto add = [&](int64_t rows) { const int64_t pb = (rows + ELL_RB / 2) / ELL_RB; if (pb >= 8 && pb < (1 << 24)) cand.push_back((int)pb); };
+    for (int i = 0; i < n_off; ++i) { add(mag[i]); for (int j = 0; j < i; ++j) add(std::llabs(mag[i] - mag[j])); }
+    std::sort(cand.begin(), cand.end());
+    cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+    int best = 0, best_bad = n_off + 1; int64_t best_res = 0;
+    for (int pb : cand) {
+        const int64_t P = (int64_t)pb * ELL_RB;
+        int bad = 0; int64_t res = 0;
+        for (int i = 0; i < n_off; ++i) {
+            const int64_t m = mag[i] % P, r = std::min(m, P - m);
+            if (r > P / 8) ++bad; else res = std::max(res, r);
+        }
+        if (bad > n_off / 4) continue;
+        if (bad < best_bad || (bad == best_bad && res < best_res)) { best = pb; best_bad = bad; best_res = res; }
+    }
+    return best;
+}
+
 static int ell_env(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static int g_ell_on = ell_env("ITS_SPMV_ELL", 1);
 static int g_ell_grid = ell_env("ITS_SPMV_ELL_GRID", 512);
@@ -414,7 +447,7 @@ void launch_sweep_ell_view(const CsrDev &L, const SweepEll &v, double *x, const 
 {
     CsrDev V;
     V.n_rows = v.cnt; V.n_cols = L.n_cols; V.off_dict = L.off_dict; V.n_off = L.n_off;
-    V.ell_val = v.val; V.ell_idx = v.idx; V.ell_w = v.w; V.ell_blocks = v.blocks; V.ell_kind = v.kind; V.ell_pb = 0;
+    V.ell_val = v.val; V.ell_idx = v.idx; V.ell_w = v.w; V.ell_blocks = v.blocks; V.ell_kind = v.kind; V.ell_pb = v.pb;
     SpmvArgs a; a.x = x + v.lo; a.y = x + v.lo; a.b = rhs + v.lo; a.D = D + v.lo;
     launch_spmv_ell(V, a, EPI_SWEEP, s);
 }

@@ -140,7 +140,8 @@ const char *spmv_exact_kernel_name(const CsrDev &A, const SpmvArgs &a, int epilo
 bool spmv_valdict_selected(const CsrDev &A);            // option "spmv_valdict" applies to this matrix
 bool spmv_ell_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);
 // ELL image of one contiguous sweep level of crs_L (its_api.hip build_levels, its_ell.hip launch_sweep_ell_view)
-struct SweepEll { double *val = nullptr; uint32_t *idx = nullptr; int w = 0, blocks = 0, kind = 0, lo = 0, cnt = 0; };
+struct SweepEll { double *val = nullptr; uint32_t *idx = nullptr; int w = 0, blocks = 0, kind = 0, lo = 0, cnt = 0, pb = 0; };
+int ell_choose_period(const int *dict, int n_off);    // row blocks per period of the ELL work map, 0 = none (its_ell.hip)
 void launch_sweep_ell_view(const CsrDev &L, const SweepEll &v, double *x, const double *rhs, const double *D, hipStream_t s);
 bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);     // its_panel.hip
 void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
