@@ -509,6 +509,12 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->sweep_ell = value;
         return ITS_OK;
     }
+    if (!strcmp(name, "gs_first_level_fused")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "gs_first_level_fused: 0 or 1");
+        h->gs_first_level_fused = value;
+        h->ahead = false;
+        return ITS_OK;
+    }
     if (!strcmp(name, "fused_residual")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "fused_residual: 0 or 1");
         h->fused_residual = value;
@@ -803,11 +809,11 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
 }
 
 // forward solve (D+L) x = rhs, level by level (kernels.hpp:451-473); x may alias rhs
-static int sweep(its_handle *h, double *x, const double *rhs)
+static int sweep(its_handle *h, double *x, const double *rhs, int first_level = 0)
 {
     const CsrDev &L = h->mat[ITS_MAT_L];
     const bool dist = its_dist_active(h);
-    for (int l = 0; l < h->n_levels; ++l) {
+    for (int l = first_level; l < h->n_levels; ++l) {
         const int cnt = h->level_ptr[l + 1] - h->level_ptr[l];
         if (h->level_empty_lo[l] >= 0 && h->sweep_stream) {
             const int lo = h->level_empty_lo[l];
@@ -1080,14 +1086,26 @@ static int trip_gs(its_handle *h, double *res_out)
     const bool fused = h->fused_residual && Um.nnz == Am.n_upper && Um.n_upper == Um.nnz &&
                        Um.upper_col_sum == Am.upper_col_sum && Um.upper_val_xor == Am.upper_val_xor &&
                        (Am.max_row_len <= IRR_ROW_LEN || spmv_panel_eligible(Am, u, EPI_GS_FUSED)) && !its_dist_active(h);
+    // first sweep level without entries in L (the first colour): its rows' next iterate is (b - U x) / D, which the fused
+    // pass can store itself (ELL kernels) — into x_b, because other rows of that pass still read the current x
+    const int lo0 = h->n_levels >= 2 ? h->level_empty_lo[0] : -1, hi0 = lo0 >= 0 ? lo0 + (h->level_ptr[1] - h->level_ptr[0]) : -1;
+    SpmvArgs f; f.x = h->x; f.y = h->tmp; f.b = h->b; f.part_sum = h->part[0];
+    const bool pre = fused && h->gs_first_level_fused && h->sweep_stream && lo0 >= 0 && (lo0 & 1) == 0 &&
+                     ((hi0 & 1) == 0 || hi0 == Am.n_rows) && spmv_ell_eligible(Am, f, EPI_GS_FUSED);
     if (!(fused && h->ahead)) {
         if ((rc = spmv_dispatch(h, h->mat[ITS_MAT_U], u, EPI_GS_RHS, ITS_FMT_CSR_EXACT))) return rc;   // gauss_seidel.hpp:144,177
+        h->ahead_pre = false;
     }
-    if ((rc = sweep(h, h->x, h->tmp))) return rc;                                      // :227
+    if (h->ahead_pre) {
+        if ((rc = sweep(h, h->x_b, h->tmp, 1))) return rc;                             // level 0 is already there
+        std::swap(h->x, h->x_b);
+        h->ahead_pre = false;
+    } else if ((rc = sweep(h, h->x, h->tmp))) return rc;                               // :227
     if (fused) {
-        SpmvArgs f; f.x = h->x; f.y = h->tmp; f.b = h->b; f.part_sum = h->part[0];
+        f.x = h->x;
+        if (pre) { f.y2 = h->x_b; f.y2_lo = lo0; f.y2_hi = hi0; f.D = h->D; }
         if ((rc = spmv_dispatch(h, h->mat[ITS_MAT_A], f, EPI_GS_FUSED, ITS_FMT_CSR_EXACT))) return rc;
-        h->ahead = true;
+        h->ahead = true; h->ahead_pre = pre;
         return finish_scalar(h, h->part[0], res_out, FIN_SQRT);
     }
     SpmvArgs q; q.x = h->x; q.y = nullptr; q.b = h->b; q.part_sum = h->part[0];         // norm only

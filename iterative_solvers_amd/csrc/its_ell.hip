@@ -84,6 +84,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ell_kernel(
         if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) ELL_LD2(e0, a.b);
         if (EPI == EPI_JACOBI_SHIPPED) { ELL_LD2(e0, a.D); ELL_LD2(e1, a.x); ELL_LD2(e2, a.b); }
         if (EPI == EPI_SWEEP) { ELL_LD2(e0, a.b); ELL_LD2(e1, a.D); }
+        const bool pre = EPI == EPI_GS_FUSED && a.y2 && row0 >= a.y2_lo && row0 < a.y2_hi;   // rows of the entry-free first level
+        if (pre) ELL_LD2(e1, a.D);
 #undef ELL_LD2
         int c[W][2];
 #pragma unroll
@@ -108,6 +110,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ell_kernel(
             outv[r] = 0.0;
             if (r == 0 ? any : full) outv[r] = row_finish<EPI, DOT>(acc, acc2, diag, e0[r], e1[r], e2[r], lane_sum, lane_max);
         }
+        if (pre) {                                              // next iterate of these rows: (b - U x) / D, as sweep_empty_kernel
+            if (full) { ell_v2d o2; o2.x = (outv[0] - 0.0) / e1[0]; o2.y = (outv[1] - 0.0) / e1[1]; *reinterpret_cast<ell_v2d *>(a.y2 + row0) = o2; }
+            else if (any) a.y2[row0] = (outv[0] - 0.0) / e1[0];
+        } else
         if (a.y) {                                              // y == nullptr: only the norm is wanted
             if (full) {
                 ell_v2d o2; o2.x = outv[0]; o2.y = outv[1];
@@ -190,6 +196,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ellw_kernel(
         if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) ELL_LD2(e0, a.b);
         if (EPI == EPI_JACOBI_SHIPPED) { ELL_LD2(e0, a.D); ELL_LD2(e1, a.x); ELL_LD2(e2, a.b); }
         if (EPI == EPI_SWEEP) { ELL_LD2(e0, a.b); ELL_LD2(e1, a.D); }
+        const bool pre = EPI == EPI_GS_FUSED && a.y2 && row0 >= a.y2_lo && row0 < a.y2_hi;   // rows of the entry-free first level
+        if (pre) ELL_LD2(e1, a.D);
 #undef ELL_LD2
         double acc[2] = {0.0, 0.0}, acc2[2] = {0.0, 0.0}, diag[2] = {0.0, 0.0};
 #pragma unroll
@@ -220,6 +228,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ellw_kernel(
         double outv[2] = {0.0, 0.0};
         if (any) outv[0] = row_finish<EPI, DOT>(acc[0], acc2[0], diag[0], e0[0], e1[0], e2[0], lane_sum, lane_max);
         if (full) outv[1] = row_finish<EPI, DOT>(acc[1], acc2[1], diag[1], e0[1], e1[1], e2[1], lane_sum, lane_max);
+        if (pre) {
+            if (full) { ell_v2d o2; o2.x = (outv[0] - 0.0) / e1[0]; o2.y = (outv[1] - 0.0) / e1[1]; *reinterpret_cast<ell_v2d *>(a.y2 + row0) = o2; }
+            else if (any) a.y2[row0] = (outv[0] - 0.0) / e1[0];
+        } else
         if (a.y) {
             if (full) {
                 ell_v2d o2; o2.x = outv[0]; o2.y = outv[1];

@@ -79,6 +79,11 @@ struct its_handle {
     int fused_residual = 1;
     int dist_overlap = 0;                        // option "dist_overlap": halo exchange beside the interior SpMV (its_dist.hip)
     bool ahead = false;
+    // GS, fused pass on an ELL kernel, first sweep level without entries in L (first colour): that pass also stores the
+    // level's next iterate (b - U x) / D into x_b, the sweep continues there from level 1 and x / x_b swap (option
+    // "gs_first_level_fused", same bits).  ahead_pre = x_b holds it (only meaningful while `ahead`).
+    bool ahead_pre = false;
+    int gs_first_level_fused = 1;
     bool setup_done = false, residual_done = false;
     double last_residual = 0.0;
     int watch_window_ms = 50;                    // option "watch_window_ms": how long its_iterate watches before it synchronizes

@@ -121,6 +121,10 @@ struct SpmvArgs {
     int row_begin = 0, row_end = -1;
     int part_accum = 0;            // add this launch's partial to part_sum/part_max instead of overwriting
     int map_mode = 0;              // work map of the stream kernel (see spmv_stream2_kernel)
+    // EPI_GS_FUSED on the ELL kernels: rows [y2_lo, y2_hi) — the sweep's first level when its rows have no entries in L —
+    // store (b - U x) / D, i.e. their next iterate, to y2 instead of b - U x to y (y2_lo even; y2_hi even or n_rows)
+    double *y2 = nullptr;
+    int y2_lo = 0, y2_hi = 0;
 };
 
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);

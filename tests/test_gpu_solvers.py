@@ -279,6 +279,42 @@ def test_multicolor_sweep_on_level_ell_images_is_bit_identical(gen):
     assert np.array_equal(out[0][1], x_ref)
 
 
+@pytest.mark.parametrize("gen", ["lap3d_32", "lap2d_200", "cd27_40", "lap3d_33"])
+def test_first_colour_folded_into_the_residual_pass_is_bit_identical(gen):
+    """The first colour of a multicolour sweep reads nothing from L: its next iterate is (b - U x) / D, which the
+    one-pass-per-trip form (EPI_GS_FUSED on the ELL kernels) stores itself, into the spare iterate buffer; the sweep
+    continues there from the second colour and the buffers swap (option gs_first_level_fused = 0: the separate
+    elementwise kernel).  Identical histories; the iterate is read in the MIDDLE of the run too (an odd and an even
+    number of swaps), and equals the oracle's.  lap3d_33: colours of odd size, the form does not apply — same result."""
+    from iterative_solvers_amd import matgen
+    rp, col, val = {"lap3d_32": lambda: matgen.laplace3d_7pt(32), "lap2d_200": lambda: matgen.laplace2d_5pt(200),
+                    "cd27_40": lambda: matgen.convdiff3d_27pt(40), "lap3d_33": lambda: matgen.laplace3d_7pt(33)}[gen]()
+    n = len(rp) - 1
+    b = np.ones(n)
+    out = []
+    for pre in (1, 0):
+        xs = []
+        for trips in (6, 7, 25):
+            args = S.Args("gauss-seidel", S.LoopParams(max_iters=trips, tol=0.0), S.Flags(), "", "none")
+            sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_MULTICOLOR)
+            try:
+                sol.handle.set_option("gs_first_level_fused", pre)
+                S.preprocessing_crs(args, sol, rp, col, val, b, np.zeros(n))
+                S.solve(args, sol)
+                xs.append((args.normed_residuals[:args.loop_params.residual_count].copy(), sol.x_star.copy(), sol.perm.copy()))
+            finally:
+                sol.handle.close()
+        out.append(xs)
+    for a, c in zip(out[0], out[1]):
+        assert len(a[0]) > 3 and np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    orc.set_threads(1)
+    perm = out[0][2][2]
+    rpp, cp, vp = capi.permute_crs(rp, col, val, perm)
+    ref = orc.solve(rpp, cp, vp, b, np.zeros(n), orc.GAUSS_SEIDEL, max_iters=25, tol=0.0)
+    x_ref = np.empty(n); x_ref[perm] = ref["x_star"]
+    assert np.array_equal(out[0][2][1], x_ref)
+
+
 def test_gs_fusion_is_refused_for_a_foreign_crs_U():
     """The one-pass GS trip takes its b - U x from A's entries right of the diagonal, which is only the same
     thing if crs_U is that part of A: count, column sum and value hash are compared, and a crs_U that differs
