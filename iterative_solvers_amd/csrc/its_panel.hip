@@ -271,6 +271,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
                 const int r = s_row[t];
                 if (t == 0 || s_row[t - 1] != r) {
                     const int row = trow0 + r;
+                    // (parking the entries an epilogue leaves out as (0, 0) while staging, as spmv_long_kernel does, instead of
+                    // the selects of chain_step in the walk: no gain here — Jacobi trip 1.263 vs 1.277 ms — the walk waits for LDS)
                     double acc = s_acc[r], acc2 = NACC == 2 ? s_acc[PAN_TR + r] : 0.0, dg = 0.0;
                     int j = t;
                     do { chain_step<EPI>(COLS ? s_col[j] : 0, row, s_v[j], s_x[j], acc, acc2, dg); ++j; } while (j < m && s_row[j] == r);
@@ -322,14 +324,21 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
 constexpr int LONG_LPL = 8;                         // entries per lane per chunk
 constexpr int LONG_CHUNK = LONG_LPL * ITS_WAVE;     // 512 entries staged per trip
 
+// The walk is one serial chain executed by a whole wave, so every instruction on it costs the SIMD a full issue: what an
+// epilogue leaves out of its chain (the diagonal, or everything left of it) is therefore decided while STAGING, in
+// parallel — an excluded entry is parked as (0, 0), which the chain passes as fma(0, 0, acc) = acc, the same operation
+// chain_step performs — and the two chains of the fused forms run side by side in two lanes: lane 0 walks the masked
+// copy of the strip, lane 1 the full one, one multiply-add per entry for the wave instead of two plus four selects
+// (the fused passes over the long rows of the power-law matrix: Jacobi trip 1.36 -> 1.26 ms, multicolour GS 2.56 -> 2.49 ms).
 template <int EPI, bool DOT>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
     const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
     const int *__restrict__ rows, int n_long, SpmvArgs a)
 {
     constexpr bool COLS = EpiKind<EPI>::needs_col;
-    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][LONG_CHUNK + 8];
-    __shared__ int s_c[COLS ? ITS_BLOCK / ITS_WAVE : 1][COLS ? LONG_CHUNK + 8 : 1];
+    constexpr bool FUSED = EpiKind<EPI>::fused;
+    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][LONG_CHUNK + 8];                               // (value, x): the full chain
+    __shared__ double2 s_m[FUSED ? ITS_BLOCK / ITS_WAVE : 1][FUSED ? LONG_CHUNK + 8 : 1];        // the same with excluded entries as (0, 0)
     __shared__ double s_red[4];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int64_t wstride = (int64_t)gridDim.x * (ITS_BLOCK / ITS_WAVE);
@@ -341,8 +350,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
     for (int64_t k = (int64_t)blockIdx.x * (ITS_BLOCK / ITS_WAVE) + w; k < n_long; k += wstride) {
         const int row = rows[k];
         const int rj0 = rp[row], rj1 = rp[row + 1];
-        double acc = 0.0, acc2 = 0.0, dg = 0.0;
+        double acc1 = 0.0;                               // this lane's chain (lane 0: the epilogue's own, lane 1: the full one of the fused forms)
+        double dg_l = 0.0; int dg_at = -1;               // Jacobi forms: the diagonal entry this lane staged last, and where
         int cn[LONG_LPL], cc[LONG_LPL]; double vn[LONG_LPL], vv[LONG_LPL], xg[LONG_LPL];
+        const double2 *strip = (FUSED && l == 0) ? s_m[FUSED ? w : 0] : s_vx[w];
 #define LONG_LOAD_CV(c0v)                                                                 \
         _Pragma("unroll") for (int u = 0; u < LONG_LPL; ++u) {                            \
             const int e_ = (c0v) + l + ITS_WAVE * u;                                      \
@@ -357,17 +368,22 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
         for (int c0 = rj0; c0 < rj1; c0 += LONG_CHUNK) {
 #pragma unroll
             for (int u = 0; u < LONG_LPL; ++u) {
-                s_vx[w][l + ITS_WAVE * u] = make_double2(vv[u], xg[u]);
-                if (COLS) s_c[w][l + ITS_WAVE * u] = cc[u];
+                const int i = l + ITS_WAVE * u;
+                bool out = false;                        // left out of the epilogue's chain (chain_step, its_epilogue.h)
+                if (EpiKind<EPI>::skip_diag) { out = cc[u] == row; if (out && c0 + i < rj1) { dg_l = vv[u]; dg_at = c0 + i; } }
+                if (EpiKind<EPI>::upper_only) out = !(cc[u] > row);
+                const double2 full = make_double2(vv[u], xg[u]), masked = out ? make_double2(0.0, 0.0) : full;
+                if (FUSED) { s_vx[w][i] = full; s_m[FUSED ? w : 0][i] = masked; }
+                else s_vx[w][i] = COLS ? masked : full;
             }
             LONG_GATHER()
             LONG_LOAD_CV(c0 + 2 * LONG_CHUNK)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const int ne = min(LONG_CHUNK, rj1 - c0);
             {
-                double2 pa[8], pb[8]; int cpa[8], cpb[8]; (void)cpa; (void)cpb;
-#define LONG_RD(S, qv) _Pragma("unroll") for (int u = 0; u < 8; ++u) { S[u] = s_vx[w][(qv) + u]; if (COLS) c##S[u] = s_c[w][(qv) + u]; }
-#define LONG_FMA(S, cnt) _Pragma("unroll") for (int u = 0; u < 8; ++u) if (u < (cnt)) chain_step<EPI>(COLS ? c##S[u] : 0, row, S[u].x, S[u].y, acc, acc2, dg);
+                double2 pa[8], pb[8];
+#define LONG_RD(S, qv) _Pragma("unroll") for (int u = 0; u < 8; ++u) S[u] = strip[(qv) + u];
+#define LONG_FMA(S, cnt) _Pragma("unroll") for (int u = 0; u < 8; ++u) if (u < (cnt)) acc1 = fma(S[u].x, S[u].y, acc1);
                 int q = 0;
                 LONG_RD(pa, 0)
                 for (; q + 16 <= ne; q += 16) {
@@ -391,6 +407,16 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
         }
 #undef LONG_LOAD_CV
 #undef LONG_GATHER
+        // the diagonal the chain ends with is the LAST one staged (chain_step: diag = dg ? v : diag)
+        double dg = 0.0;
+        if (EpiKind<EPI>::skip_diag) {
+            int best = dg_at;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o, ITS_WAVE));
+            const unsigned long long who = __ballot(best >= 0 && dg_at == best);
+            if (who) dg = __shfl(dg_l, __ffsll((long long)who) - 1, ITS_WAVE);
+        }
+        const double acc = __shfl(acc1, 0, ITS_WAVE), acc2 = FUSED ? __shfl(acc1, 1, ITS_WAVE) : 0.0;
         if (l == 0) {
             double e0 = 0.0, e1 = 0.0, e2 = 0.0;
             epi_operands<EPI, DOT>(a, row, e0, e1, e2);
