@@ -29,6 +29,7 @@
 #include "its_handle.h"
 #include "its_epilogue.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -204,6 +205,10 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp)
     cleanup();
     A.pan_tiles = n_tiles; A.pan_n_long = (int)long_rows.size(); A.pan_log2pw = log2pw; A.pan_nnz = n_short;
     A.pan_chunks = (int)desc.size() - 2;
+    if (getenv("ITS_DEBUG_PANEL"))
+        fprintf(stderr, "panel image: %d tiles, %d panels, %d chunks for %lld entries (%.1f per chunk of %d), %d long rows with %lld entries\n",
+                n_tiles, P, A.pan_chunks, (long long)n_short, A.pan_chunks ? (double)n_short / A.pan_chunks : 0.0, PAN_CH,
+                (int)long_rows.size(), (long long)nnz_long);
     return ITS_OK;
 }
 

@@ -14,6 +14,7 @@ args = S.Args("gauss-seidel", S.LoopParams(max_iters=10**9, tol=0.0))
 sol = S.Solver("gauss-seidel", device=0, gs_order=order)
 sol.handle.set_option("fused_residual", int(os.environ.get("FUSED", "1")))
 sol.handle.set_option("sweep_ell_levels", int(os.environ.get("LEVELL", "1")))
+sol.handle.set_option("sweep_stream", int(os.environ.get("SWEEPSTREAM", "1")))
 S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
 h = sol.handle
 for it in range(2): h.iterate(it)
