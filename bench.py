@@ -462,6 +462,29 @@ def main():
         jb = spmv_bytes(n, nnz) + 8 * n
         out["jacobi"] = {"value": a.steps / jdt * world, "unit": out["unit"], "ms_per_step": jdt / a.steps * 1e3,
                          "GBps_algorithmic_per_gpu": jb * a.steps / jdt / 1e9}
+    # row-partitioned runs only, opt-in and never `value`: pipelined CG (its_set_option "cg_variant" 1) — one
+    # reduction point per trip instead of two — on the same resident system with the same timing protocol, so that the
+    # scaling record shows what the second all-reduce of a trip costs on this fabric.  ITS_BENCH_NO_PIPELINED=1 skips it.
+    if (world > 1 or force_dist) and os.environ.get("ITS_BENCH_NO_PIPELINED", "0") != "1":
+        h.set_option("cg_variant", 1)
+        h.upload_vectors(np.full(n, 6.0), np.ones(n), np.ones(n))
+        h.init_residual()
+        h.solver_setup(capi.CG)
+        pt = 0
+        for _ in range(a.warmup):
+            h.iterate(pt); pt += 1
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            h.iterate(pt); pt += 1
+        barrier()
+        pdt = time.perf_counter() - t0
+        if dist is not None:
+            pdt = dist.allreduce_max(pdt)
+        if rank == 0:
+            out["opt_in"] = dict(out.get("opt_in") or {}, pipelined_cg={
+                "value": a.steps / pdt * world, "unit": out["unit"], "ms_per_step": pdt / a.steps * 1e3,
+                "note": "Ghysels-Vanroose recurrence, outside the parity contract: one reduction point per trip"})
     if dist is not None:
         dist.barrier()
     h.close()
