@@ -1166,9 +1166,15 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_sell_kernel(
             _Pragma("unroll") for (int u = 0; u < 8; ++u) xv[u] = a.x[c[u]];              \
             _Pragma("unroll") for (int u = 0; u < 8; ++u) acc = fma(v[u], xv[u], acc);    \
         }                                                                                 \
-        for (; j < (jb); ++j) {                                                           \
-            const int64_t idx = (cs) + (int64_t)j * 64 + lane;                            \
-            acc = fma(sval[idx], a.x[scol[idx]], acc);                                    \
+        if (j < (jb)) {        /* the last 1..7 columns as one guarded batch (not one dependent round trip each) */ \
+            int c[8]; double v[8], xv[8];                                                 \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                               \
+                const int64_t idx = (cs) + (int64_t)(j + u) * 64 + lane;                  \
+                c[u] = 0; v[u] = 0.0;                                                     \
+                if (j + u < (jb)) { c[u] = scol[idx]; v[u] = sval[idx]; }                 \
+            }                                                                             \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) xv[u] = (j + u < (jb)) ? a.x[c[u]] : 0.0; \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) if (j + u < (jb)) acc = fma(v[u], xv[u], acc); \
         }                                                                                 \
     }
 #define SELL_EPILOGUE(ch, acc)                                                            \
