@@ -94,6 +94,9 @@ extern "C" int its_create(its_handle **out, int device)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ITS_EHIP;
     its_handle *h = new its_handle;
     if (const char *e = getenv("ITS_DIST_OVERLAP")) h->dist_overlap = atoi(e) != 0;
+    // (for hosts that take no options of their own — its_solve: the same switches as its_set_option)
+    if (const char *e = getenv("ITS_GMRES_PERSIST")) h->gmres_persist = atoi(e) != 0;
+    if (const char *e = getenv("ITS_GMRES_PERSIST_MIN_N")) h->gmres_persist_min_n = std::max(1, atoi(e));
     if (device >= 0) { if (hipSetDevice(device) != hipSuccess) { delete h; return ITS_EHIP; } }
     (void)hipGetDevice(&h->device);
     // once per device, with that device current: the address of THIS device's copy of the no-allocation scratch
@@ -933,6 +936,7 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
             if (h->mgs_grid > 0 && dalloc(h, &h->mgs_slots, mgs_persist_slot_words(m, h->mgs_grid))) return ITS_EHIP;
             if (h->mgs_grid > 0) HIPCHK(h, mgs_persist_reset(h->mgs_slots, m, h->mgs_grid, h->stream));
         }
+        if (getenv("ITS_DEBUG_GMRES")) fprintf(stderr, "its_solver_setup(GMRES): Gram-Schmidt %s (%d workgroups), n = %d, restart %d\n", h->mgs_grid > 0 ? "as one persistent launch per trip" : "as one launch per basis vector", h->mgs_grid, n, m);
         h->restart_count = 0;
         // beta = ||r||, V[0] = r * (1/beta)   (gmres.hpp:734-736,768-771)
         launch_dot_partials(h->r, h->r, n, h->part[0], h->stream);

@@ -26,8 +26,17 @@ def _mtx(m):
     return mtx_path(m)
 
 
+@pytest.mark.parametrize("key", [k for k in CASES if "|-gm|" in k])
+def test_cli_gmres_on_the_persistent_launch_matches_reference_output(key):
+    """The same comparison with the Gram-Schmidt sweep of every GMRES trip forced onto the persistent launch
+    (csrc/its_mgs.hip; ITS_GMRES_PERSIST_MIN_N = 1 — by default these matrices are too small for it): the golden output of
+    the compiled reference, not only the oracle, pins that path."""
+    test_cli_matches_reference_output(key, extra_env={"ITS_GMRES_PERSIST_MIN_N": "1", "ITS_DEBUG_GMRES": "1"},
+                                      expect_stderr="as one persistent launch per trip")
+
+
 @pytest.mark.parametrize("key", CASES)
-def test_cli_matches_reference_output(key):
+def test_cli_matches_reference_output(key, extra_env=None, expect_stderr=None):
     """The golden histories were printed by the reference at its compiled-in TOL = 1e-14, where
     the last trips of a converging run are rounding noise (tests/test_gpu_solvers.py docstring).
     The driver is therefore run at ITS_TOL = 1e-10: its arithmetic up to the stopping trip is the
@@ -38,9 +47,10 @@ def test_cli_matches_reference_output(key):
     restart, pre = int(mm[1:]), pp[1:]
     exp = HIST[key]
     cmd = [EXE, _mtx(m), s] + (["-p", pre] if pre else ["-scale", sc])
-    env = dict(os.environ, ITS_GMRES_RESTART_LEN=str(restart), ITS_TOL="1e-10")
+    env = dict(os.environ, ITS_GMRES_RESTART_LEN=str(restart), ITS_TOL="1e-10", **(extra_env or {}))
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stdout + out.stderr
+    assert expect_stderr is None or expect_stderr in out.stderr, out.stderr[-400:]
     try:
         _compare(key, out.stdout, exp, m, s, sc, restart, pre)
     except AssertionError as first:
