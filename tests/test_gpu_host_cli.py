@@ -35,6 +35,16 @@ def test_cli_gmres_on_the_persistent_launch_matches_reference_output(key):
                                       expect_stderr="as one persistent launch per trip")
 
 
+@pytest.mark.parametrize("key", [k for k in CASES if k.startswith("pl_200|")])
+def test_cli_on_the_panel_blocked_kernels_matches_reference_output(key):
+    """The power-law cases with the column-panel blocked image (csrc/its_panel.hip) forced onto the 200-row matrix — panels
+    of 32 columns, rows of more than 16 entries on the long-row launch: SpMV, residual, Jacobi and GS passes of `its_solve`
+    then run on spmv_panel_kernel / spmv_long_kernel, and the output is compared with the compiled reference's."""
+    test_cli_matches_reference_output(key, extra_env={"ITS_SPMV_PANEL_MIN_COLS": "1", "ITS_SPMV_PANEL_LOG2PW": "5",
+                                                      "ITS_SPMV_PANEL_LCUT": "16", "ITS_DEBUG_PANEL": "1"},
+                                      expect_stderr="panel image:")
+
+
 @pytest.mark.parametrize("key", CASES)
 def test_cli_matches_reference_output(key, extra_env=None, expect_stderr=None):
     """The golden histories were printed by the reference at its compiled-in TOL = 1e-14, where
