@@ -102,7 +102,8 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                  be resident (another process on the GPU) gives up after 20 ms and the trip is repeated the other way.
  *   "fused_residual" 1 (default) = a Jacobi / Gauss-Seidel trip reads A once: the pass that records
  *                  ||b - A x_new|| (utility_funcs.hpp:423-447) also produces the next trip's product of
- *                  x_new (second in-order chain per row); 0 = separate launches.  Same bits either way.
+ *                  x_new (second in-order chain per row; the shipped Jacobi sweep works on the full product, so there
+ *                  the one chain serves both); 0 = separate launches.  Same bits either way.
  *   "gs_first_level_fused" 1 (default) = when the first level of the sweep has no entries in L (the first colour of a
  *                  multicolour order) and A runs on the ELL kernels, the one pass over A also stores that level's next
  *                  iterate (b - U x) / D; the sweep starts at the second level; 0 = separate kernel.  Same bits.

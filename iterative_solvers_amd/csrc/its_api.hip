@@ -1062,6 +1062,24 @@ static int trip_jacobi(its_handle *h, double *res_out)
         h->ahead = true;
         return ITS_OK;
     }
+    if (h->jacobi_mode == ITS_JACOBI_SHIPPED && h->fused_residual) {
+        // The shipped sweep's chain IS the full row (jacobi.hpp:41-62 works on A x): the pass that sweeps x_new into the
+        // iterate after it walks exactly the chain of ||b - A x_new||, so it records that norm as well — one pass over A
+        // and one chain per trip, same bits as the sweep and the residual pass apart.
+        if (!h->ahead) {
+            a.x = h->x_a;
+            if ((rc = solver_spmv(h, a, EPI_JACOBI_SHIPPED))) return rc;
+        }
+        SpmvArgs f; f.x = h->x_b; f.y = h->x; f.b = h->b; f.D = h->D; f.part_sum = h->part[0];
+        if ((rc = solver_spmv(h, f, EPI_JACOBI_SHIPPED))) return rc;
+        if ((rc = finish_scalar(h, h->part[0], res_out, FIN_SQRT))) return rc;
+        double *spare = h->x_a;
+        h->x_a = h->x_b;                                              // exchange_arrays: the new iterate
+        h->x_b = h->x;                                                // the iterate after it
+        h->x = spare;
+        h->ahead = true;
+        return ITS_OK;
+    }
     if (h->jacobi_mode == ITS_JACOBI_SHIPPED) {
         a.x = h->x_a;
         rc = solver_spmv(h, a, EPI_JACOBI_SHIPPED);

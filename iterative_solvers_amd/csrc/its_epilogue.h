@@ -21,7 +21,9 @@ template <int EPI> struct EpiKind {
     static constexpr bool skip_diag = EPI == EPI_JACOBI_REF || EPI == EPI_JACOBI_FUSED;
     static constexpr bool upper_only = EPI == EPI_GS_FUSED;
     static constexpr bool fused = EPI == EPI_JACOBI_FUSED || EPI == EPI_GS_FUSED;
-    static constexpr bool norm = EPI == EPI_RESIDUAL || fused;          // writes r^2 / max|r| partials
+    // writes r^2 / max|r| partials.  EPI_JACOBI_SHIPPED too: its chain is the full row, i.e. the chain of the residual of
+    // the vector it multiplies, so the pass that sweeps x also records ||b - A x|| when it is given part_sum
+    static constexpr bool norm = EPI == EPI_RESIDUAL || fused || EPI == EPI_JACOBI_SHIPPED;
     static constexpr bool needs_col = skip_diag || upper_only;
 };
 
@@ -70,6 +72,9 @@ __device__ __forceinline__ double row_finish(double acc, double acc2, double dia
     } else if (EPI == EPI_JACOBI_SHIPPED) {
         const double adj = fma(-e0, acc, e1);
         outv = (e2 - adj) / e0;
+        const double r = e2 - acc;                  // b - A x of the swept vector, as EPI_RESIDUAL
+        lane_sum = fma(r, r, lane_sum);
+        lane_max = fmax(lane_max, fabs(r));
     } else if (EPI == EPI_JACOBI_REF || EPI == EPI_JACOBI_FUSED) {
         outv = (e0 - acc) / diag;
     } else if (EPI == EPI_SWEEP) {

@@ -183,6 +183,32 @@ def test_gauss_seidel_multicolor(name):
     assert np.max(np.abs(xs - x_ref)) <= 1e-12 * max(1.0, np.max(np.abs(x_ref)))
 
 
+@pytest.mark.parametrize("name", ["lap3d_16", "cd27_12", "pl_200", "pl_5000", "lap2d_64"])
+def test_shipped_jacobi_one_pass_per_trip_is_bit_identical(name):
+    """The shipped Jacobi sweep (jacobi.hpp:41-62, the reference's default) works on the full product A x, the chain of
+    the residual of the same vector: the pass that sweeps x_new also records ||b - A x_new|| (EPI_JACOBI_SHIPPED with
+    partial sums).  Same bits as sweep + residual pass (fused_residual = 0); the iterate is read after an odd and an even
+    number of trips (the three iterate buffers rotate)."""
+    rp, col, val = MATRICES[name]()
+    n = len(rp) - 1
+    out = []
+    for fused in (1, 0):
+        runs = []
+        for trips in (30, 31):
+            args = S.Args("jacobi", S.LoopParams(max_iters=trips, tol=1e-13), S.Flags(), "", "none")
+            sol = S.Solver("jacobi", device=0, jacobi_mode=0)
+            try:
+                sol.handle.set_option("fused_residual", fused)
+                S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+                S.solve(args, sol)
+                runs.append((args.normed_residuals[:args.loop_params.residual_count].copy(), sol.x_star.copy()))
+            finally:
+                sol.handle.close()
+        out.append(runs)
+    for a, c in zip(out[0], out[1]):
+        assert len(a[0]) > 3 and np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
 @pytest.mark.parametrize("valdict", [0, 1])
 @pytest.mark.parametrize("name", ["lap3d_16", "cd27_6", "pl_200", "pl_5000"])
 @pytest.mark.parametrize("flag", ["-j", "-gs"])
