@@ -920,7 +920,7 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         h->cs.assign(m, 0.0); h->sn.assign(m, 0.0); h->hcol.assign(m + 2, 0.0);
         if (const char *e = getenv("ITS_GMRES_GIVENS")) h->gmres_givens = !strcmp(e, "dense") || !strcmp(e, "1");
         if (h->gmres_givens == 1) {
-            h->Hd.assign((size_t)(m + 1) * m, 0.0); h->Ht = h->Hd; h->Rd = h->Hd;
+            h->Hd.assign((size_t)(m + 1) * m, 0.0); h->Ht = h->Hd; h->Rd = h->Hd; h->dense_full = false;
             h->Qd.assign((size_t)(m + 1) * (m + 1), 0.0); h->Jd = h->Qd; h->Qc = h->Qd;
             for (int i = 0; i <= m; ++i) h->Qd[(size_t)i * (m + 1) + i] = 1.0;
         }
@@ -1238,17 +1238,56 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
                 }
         };
         for (int i = 0; i <= k + 1; ++i) h->Hd[(size_t)i * m + k] = hc[i];          // H row-major (m+1) x m, column k
-        std::fill(h->Jd.begin(), h->Jd.end(), 0.0);
-        for (int i = 0; i < m1; ++i) h->Jd[(size_t)i * m1 + i] = 1.0;
-        if (k == 0) h->Ht = h->Hd; else mm(h->Qd.data(), h->Hd.data(), h->Ht.data(), m1, m1, m);
-        const double hkk = h->Ht[(size_t)k * m + k], hk1 = h->Ht[(size_t)(k + 1) * m + k];
-        const double denom = std::sqrt(std::fma(hkk, hkk, hk1 * hk1));
-        const double c = hkk / denom, s = hk1 / denom;
-        h->Jd[(size_t)k * m1 + k] = c;            h->Jd[(size_t)k * m1 + k + 1] = s;
-        h->Jd[(size_t)(k + 1) * m1 + k] = -1.0 * s; h->Jd[(size_t)(k + 1) * m1 + k + 1] = c;
-        mm(h->Jd.data(), h->Qd.data(), h->Qc.data(), m1, m1, m1);
-        h->Qd = h->Qc;
-        mm(h->Qd.data(), h->Hd.data(), h->Rd.data(), m1, m1, m);
+        // The products as the reference writes them are O(m^3) per trip; almost all of their chains repeat last trip's
+        // operands or multiply by rows of the identity.  What can change is computed, with the reference's own chains
+        // (every term, in order), the rest is kept: J differs from I in rows k, k+1 only, so Q <- J Q rewrites those two
+        // rows (the chain of any other row is fma(0, ., t) ... fma(1, Q_ij, +0) ... = Q_ij); of H_tmp = Q H only entries
+        // (k, k) and (k+1, k) are read; R = Q H changes in rows k, k+1 (new rows of Q) and in column k (new column of H).
+        // O(m^2) per trip, the same bits (tests/test_gpu_state.py runs both; ITS_GMRES_DENSE_FULL=1 keeps the full
+        // products).  A non-finite entry (fma(0, inf) = NaN would spread through the full products) switches the rest of
+        // the cycle to them.
+        static const bool always_full = getenv("ITS_GMRES_DENSE_FULL") != nullptr;
+        bool finite = true;
+        for (int i = 0; i <= k + 1; ++i) finite = finite && std::isfinite(hc[i]);
+        if (!finite) h->dense_full = true;
+        auto chain = [&](const double *Arow, const double *Bcol, int stride) {      // sum_q A[q] * B[q * stride], q = 0 .. m
+            double t = 0.0;
+            for (int q = 0; q < m1; ++q) t = std::fma(Arow[q], Bcol[(size_t)q * stride], t);
+            return t;
+        };
+        if (always_full || h->dense_full) {
+            std::fill(h->Jd.begin(), h->Jd.end(), 0.0);
+            for (int i = 0; i < m1; ++i) h->Jd[(size_t)i * m1 + i] = 1.0;
+            if (k == 0) h->Ht = h->Hd; else mm(h->Qd.data(), h->Hd.data(), h->Ht.data(), m1, m1, m);
+            const double hkk = h->Ht[(size_t)k * m + k], hk1 = h->Ht[(size_t)(k + 1) * m + k];
+            const double denom = std::sqrt(std::fma(hkk, hkk, hk1 * hk1));
+            const double c = hkk / denom, s = hk1 / denom;
+            h->Jd[(size_t)k * m1 + k] = c;            h->Jd[(size_t)k * m1 + k + 1] = s;
+            h->Jd[(size_t)(k + 1) * m1 + k] = -1.0 * s; h->Jd[(size_t)(k + 1) * m1 + k + 1] = c;
+            mm(h->Jd.data(), h->Qd.data(), h->Qc.data(), m1, m1, m1);
+            h->Qd = h->Qc;
+            mm(h->Qd.data(), h->Hd.data(), h->Rd.data(), m1, m1, m);
+        } else {
+            const double hkk = k == 0 ? h->Hd[(size_t)k * m + k] : chain(&h->Qd[(size_t)k * m1], &h->Hd[k], m);
+            const double hk1 = k == 0 ? h->Hd[(size_t)(k + 1) * m + k] : chain(&h->Qd[(size_t)(k + 1) * m1], &h->Hd[k], m);
+            const double denom = std::sqrt(std::fma(hkk, hkk, hk1 * hk1));
+            const double c = hkk / denom, s = hk1 / denom;
+            if (!std::isfinite(c) || !std::isfinite(s)) h->dense_full = true;   // (this trip is still what the full products give: NaN rows k, k+1; from the next one on it spreads)
+            // rows k, k+1 of J Q: terms q = k, k+1 of the chain, in that order; every other term adds an exact zero
+            double *Qk = &h->Qd[(size_t)k * m1], *Qk1 = &h->Qd[(size_t)(k + 1) * m1];
+            const double ms = -1.0 * s;
+            for (int j = 0; j < m1; ++j) {
+                const double a0 = Qk[j], a1 = Qk1[j];
+                Qk[j] = std::fma(s, a1, std::fma(c, a0, 0.0));
+                Qk1[j] = std::fma(c, a1, std::fma(ms, a0, 0.0));
+            }
+            // R = Q H: rows k, k+1 for the columns filled so far, column k for every row
+            for (int j = 0; j <= k; ++j) {
+                h->Rd[(size_t)k * m + j] = chain(Qk, &h->Hd[j], m);
+                h->Rd[(size_t)(k + 1) * m + j] = chain(Qk1, &h->Hd[j], m);
+            }
+            for (int i = 0; i < m1; ++i) h->Rd[(size_t)i * m + k] = chain(&h->Qd[(size_t)i * m1], &h->Hd[k], m);
+        }
         for (int i = 0; i < m1; ++i) h->g[i] = h->Qd[(size_t)i * m1] * h->beta;   // Q (beta e1): the chain's other terms are exact zeros
         for (int c2 = 0; c2 <= k; ++c2)                                           // keep Rm (col-major) for gmres_get_x
             for (int i = 0; i <= c2; ++i) h->Rm[(size_t)c2 * m1 + i] = h->Rd[(size_t)i * m + c2];
@@ -1417,6 +1456,8 @@ extern "C" int its_gmres_restart(its_handle *h, int iter_count)
     std::fill(h->Rm.begin(), h->Rm.end(), 0.0);
     if (h->gmres_givens == 1) {                                        // init_gmres_structs (gmres.hpp:773-779)
         std::fill(h->Hd.begin(), h->Hd.end(), 0.0);
+        std::fill(h->Rd.begin(), h->Rd.end(), 0.0);
+        h->dense_full = false;
         std::fill(h->Qd.begin(), h->Qd.end(), 0.0);
         for (int i = 0; i <= h->m; ++i) h->Qd[(size_t)i * (h->m + 1) + i] = 1.0;
     }

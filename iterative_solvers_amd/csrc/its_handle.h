@@ -46,6 +46,7 @@ struct its_handle {
     // dense least-squares state of the reference formulation (gmres_givens == 1)
     std::vector<double> Hd, Qd, Jd, Qc, Ht, Rd;
     int gmres_givens = 0;                 // 0: O(m) rotation updates, 1: the reference's dense products
+    bool dense_full = false;              // dense formulation: the rest of this cycle runs the full products (a non-finite entry was seen)
     // communication-reducing variants (its_krylov_cr.hip), opt-in: "cg_variant" 1 = pipelined CG, "gmres_ortho" 1 = CGS-2
     int cg_variant = 0, gmres_ortho = 0;
     // persistent modified Gram-Schmidt (its_mgs.hip): option "gmres_persist" (1), for vectors of at least

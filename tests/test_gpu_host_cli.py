@@ -45,6 +45,23 @@ def test_cli_on_the_panel_blocked_kernels_matches_reference_output(key):
                                       expect_stderr="panel image:")
 
 
+@pytest.mark.parametrize("m,restart,pre", [("lap2d_64", 100, ""), ("cd27_12", 30, ""), ("lap3d_16", 7, ""), ("pl_200", 10, "gs")])
+def test_cli_dense_givens_incremental_equals_the_full_products(m, restart, pre):
+    """its_solve runs the reference's dense least-squares formulation (gmres.hpp:427-658).  The library computes only the
+    chains of those products whose operands changed since the last trip (O(m^2) per trip); ITS_GMRES_DENSE_FULL=1 runs
+    every chain of every product (O(m^3)).  The printed histories must be the same text, restarts included."""
+    cmd = [EXE, _mtx(m), "-gm"] + (["-p", pre] if pre else ["-scale", "none"])
+    outs = []
+    for full in (False, True):
+        env = dict(os.environ, ITS_GMRES_RESTART_LEN=str(restart), ITS_TOL="1e-13", ITS_MAX_ITERS="260")
+        if full:
+            env["ITS_GMRES_DENSE_FULL"] = "1"
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+        assert out.returncode == 0, out.stdout + out.stderr
+        outs.append(LINE.findall(out.stdout))
+    assert len(outs[0]) > restart and outs[0] == outs[1]
+
+
 @pytest.mark.parametrize("key", CASES)
 def test_cli_matches_reference_output(key, extra_env=None, expect_stderr=None):
     """The golden histories were printed by the reference at its compiled-in TOL = 1e-14, where
