@@ -111,6 +111,9 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                  stream beside the interior row blocks, boundary blocks afterwards.  Same values.
  *   "sweep_stream" 1 (default) = sweep levels that are contiguous row ranges (the colours of a multicolour
  *                  ordering) run on the exact SpMV kernels; 0 = level-list kernels only.  Same bits.
+ *   "sweep_run"    1 (default) = consecutive levels of at most 1024 rows of a natural-order sweep of short rows (all
+ *                  levels of a 2-D stencil, the first and last ones of a 3-D one) run as ONE launch of one workgroup with
+ *                  a barrier between levels instead of a launch per level; 0 = a launch per level.  Same bits.
  *   "sweep_ell_levels" 1 (default) = such a level gets an ELL image of its own rows of crs_L when they are short and
  *                  regular (colours of a stencil: nibble or byte dictionary indices, as for "spmv_ell"), built at
  *                  its_solver_setup; a level whose rows have no entries is one elementwise kernel.  Same bits.

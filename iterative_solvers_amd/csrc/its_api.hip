@@ -133,7 +133,7 @@ extern "C" int its_destroy(its_handle *h)
     dfree(h->pcg_w); dfree(h->pcg_s); dfree(h->pcg_z); dfree(h->pcg_pair[0]); dfree(h->pcg_pair[1]); dfree(h->gram_part); dfree(h->gram_h); dfree(h->mgs_slots);
     for (auto &e : h->prof_ev) (void)hipEventDestroy(e);
     for (auto &p : h->part) dfree(p);
-    dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows); dfree(h->sweep_desc); free_level_ell(h);
+    dfree(h->sc); dfree(h->res_dev); dfree(h->level_rows); dfree(h->level_ptr_dev); dfree(h->sweep_desc); free_level_ell(h);
     dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D);
     if (h->pinned) (void)hipHostFree(h->pinned);
     (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
@@ -509,6 +509,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->sweep_ell_levels = value;
         return ITS_OK;
     }
+    if (!strcmp(name, "sweep_run")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_run: 0 or 1");
+        h->sweep_run = value;
+        return ITS_OK;
+    }
     if (!strcmp(name, "sweep_ell")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_ell: 0 or 1");
         h->sweep_ell = value;
@@ -810,6 +815,23 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
             h->sw_w = W;
         }
     }
+    // runs of consecutive levels that the level-ordered copy serves and that fit one workgroup
+    dfree(h->level_ptr_dev); h->level_run_end.assign(nl, 0);
+    if (h->sw_w > 0 && nl > 0) {
+        if (dalloc(h, &h->level_ptr_dev, (size_t)nl + 1)) return ITS_EHIP;
+        HIPCHK(h, hipMemcpy(h->level_ptr_dev, h->level_ptr.data(), ((size_t)nl + 1) * sizeof(int), hipMemcpyHostToDevice));
+        auto small = [&](int l) {
+            return h->level_desc_count[l] == 0 && h->level_empty_lo[l] < 0 && !h->level_ell[l].val &&
+                   h->level_ptr[l + 1] - h->level_ptr[l] <= sweep_run_rows();
+        };
+        for (int l = 0; l < nl;) {
+            if (!small(l)) { ++l; continue; }
+            int e = l;
+            while (e < nl && small(e)) ++e;
+            if (e - l >= 2) h->level_run_end[l] = e;
+            l = e;
+        }
+    }
     return ITS_OK;
 }
 
@@ -828,6 +850,11 @@ static int sweep(its_handle *h, double *x, const double *rhs, int first_level = 
         } else if (h->level_desc_count[l] > 0 && h->sweep_stream) {
             SpmvArgs a; a.x = x; a.y = x; a.b = rhs; a.D = h->D;   // rows of a level never read each other's x
             launch_spmv_exact_desc(L, h->sweep_desc + h->level_desc_first[l], h->level_desc_count[l], a, EPI_SWEEP, 0, h->stream);
+        } else if (h->sw_w > 0 && h->sweep_ell && h->sweep_run && !dist && h->level_run_end[l] > l) {
+            const int e = h->level_run_end[l];
+            launch_sweep_ell_run(L.n_rows, h->sw_w, l, e, h->level_ptr_dev, h->level_rows, h->sw_col, h->sw_val, h->sw_D, x, rhs, h->stream);
+            l = e - 1;
+            continue;
         } else if (h->sw_w > 0 && h->sweep_ell) {
             launch_sweep_ell_level(L.n_rows, h->sw_w, h->level_ptr[l], h->level_ptr[l + 1], h->level_rows, h->sw_col, h->sw_val,
                                    h->sw_D, x, rhs, h->stream);

@@ -107,6 +107,10 @@ struct its_handle {
     int *sw_col = nullptr; double *sw_val = nullptr, *sw_D = nullptr;
     int sw_w = 0;                         // 0: not built
     int sweep_ell = 1;                    // option "sweep_ell"
+    // runs of consecutive small levels of that copy go out as one launch of one workgroup (option "sweep_run")
+    int *level_ptr_dev = nullptr;         // device copy of level_ptr (only with the level-ordered copy)
+    std::vector<int> level_run_end;       // per level: one past the last level of the run that starts here (0: no run starts here)
+    int sweep_run = 1;
     int *level_rows = nullptr;            // device
     int n_levels = 0;
     // multicolour permutation (gs_order == ITS_GS_MULTICOLOR): new index -> old index

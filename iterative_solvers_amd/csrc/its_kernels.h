@@ -233,6 +233,10 @@ void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int 
 constexpr int SWEEP_ELL_W = 8;
 void launch_sweep_ell_build(int n, int W, const int *rows, const CsrDev &L, const double *D, int *sw_col, double *sw_val,
                             double *sw_D, hipStream_t s);
+// a run of consecutive levels of at most sweep_run_rows() list positions each, in one launch of one workgroup
+int sweep_run_rows();
+void launch_sweep_ell_run(int n, int W, int l0, int l1, const int *level_ptr_dev, const int *rows, const int *sw_col,
+                          const double *sw_val, const double *sw_D, double *x, const double *rhs, hipStream_t s);
 void launch_sweep_ell_level(int n, int W, int p0, int p1, const int *rows, const int *sw_col, const double *sw_val,
                             const double *sw_D, double *x, const double *rhs, hipStream_t s);
 

@@ -380,6 +380,39 @@ def test_odd_row_count(flag):
     assert np.max(np.abs(xs - ref["x_star"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["x_star"])))
 
 
+@pytest.mark.parametrize("gen", ["lap2d_256", "lap3d_48", "cd27_20", "lap2d_1100"])
+def test_runs_of_small_levels_in_one_workgroup_are_bit_identical(gen):
+    """Consecutive levels of at most 1024 rows of a natural-order sweep (all 511 of a 256 x 256 grid; the first and last
+    ones of a 3-D grid; none of the middle ones of a 1100 x 1100 grid, whose levels reach 1100 rows) run as one launch of
+    one workgroup with a barrier between levels (option sweep_run, default on) instead of a launch per level.  Same
+    histories and iterates as sweep_run = 0 for GS and for GS-preconditioned GMRES (which sweeps in place, x == rhs),
+    and the GS iterate equals the oracle's serial sweep."""
+    from iterative_solvers_amd import matgen
+    rp, col, val = {"lap2d_256": lambda: matgen.laplace2d_5pt(256), "lap3d_48": lambda: matgen.laplace3d_7pt(48),
+                    "cd27_20": lambda: matgen.convdiff3d_27pt(20), "lap2d_1100": lambda: matgen.laplace2d_5pt(1100)}[gen]()
+    n = len(rp) - 1
+    out = []
+    for run in (1, 0):
+        res = []
+        for solver, precond, iters in (("gauss-seidel", "", 12), ("gmres", "gauss-seidel", 12)):
+            args = S.Args(solver, S.LoopParams(max_iters=iters, tol=1e-30, gmres_restart_len=5), S.Flags(), precond, "none")
+            sol = S.Solver(solver, precond, device=0)
+            try:
+                sol.handle.set_option("sweep_run", run)
+                S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+                S.solve(args, sol)
+                res.append((args.normed_residuals[:args.loop_params.residual_count].copy(), sol.x_star.copy()))
+            finally:
+                sol.handle.close()
+        out.append(res)
+    for a, c in zip(out[0], out[1]):
+        assert len(a[0]) > 3 and np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    if n <= 120000:
+        orc.set_threads(1)
+        ref = orc.solve(rp, col, val, np.ones(n), np.ones(n), orc.GAUSS_SEIDEL, max_iters=12, tol=1e-30)
+        assert np.array_equal(out[0][0][1], ref["x_star"])
+
+
 @pytest.mark.parametrize("name", ["lap3d_16", "lap2d_64", "cd27_6"])
 def test_natural_order_sweep_level_ordered_copy_is_bit_identical(name):
     """Natural-order Gauss-Seidel on a stencil = many dependency levels of scattered short rows: they are swept from
