@@ -45,7 +45,7 @@ static void free_level_ell(its_handle *h)
 
 static void free_csr(CsrDev &A)
 {
-    dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc); dfree(A.blk_desc_big);
+    dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc); dfree(A.blk_desc_big); dfree(A.blk_desc_short); dfree(A.irr_long_rows);
     dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict); dfree(A.vidx); dfree(A.val_dict);
     dfree(A.ell_val); dfree(A.ell_idx);
     dfree(A.pan_key); dfree(A.pan_val); dfree(A.pan_desc); dfree(A.pan_tile_ptr); dfree(A.pan_tile_row); dfree(A.pan_long); dfree(A.pan_diag); dfree(A.pan_long_rows);
@@ -335,6 +335,25 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         desc[i] = make_int4(blk[i], (blk[i + 1] - blk[i]) | (std::min(longest[i], 0x7fff) << 16), row_ptr[blk[i]], row_ptr[blk[i + 1]]);
     if (dalloc(h, &A.blk_desc, desc.size())) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.blk_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
+    // rows that do not fit a row block: out of the plan, onto the wave-per-row launch (its_kernels.h, CsrDev::blk_desc_short)
+    {
+        std::vector<int4> shortd;
+        std::vector<int> longr;
+        for (int i = 0; i < A.n_blocks; ++i) {
+            if (desc[i].w - desc[i].z > SPMV_NNZ_MAX && (desc[i].y & 0xffff) == 1) longr.push_back(desc[i].x);
+            else shortd.push_back(desc[i]);
+        }
+        if (!longr.empty() && !shortd.empty()) {
+            std::sort(longr.begin(), longr.end(), [&](int r0, int r1) {
+                const int l0 = row_ptr[r0 + 1] - row_ptr[r0], l1 = row_ptr[r1 + 1] - row_ptr[r1];
+                return l0 != l1 ? l0 > l1 : r0 < r1;
+            });
+            A.n_blocks_short = (int)shortd.size(); A.irr_n_long = (int)longr.size();
+            if (dalloc(h, &A.blk_desc_short, shortd.size()) || dalloc(h, &A.irr_long_rows, longr.size())) return ITS_EHIP;
+            HIPCHK(h, hipMemcpy(A.blk_desc_short, shortd.data(), shortd.size() * sizeof(int4), hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(A.irr_long_rows, longr.data(), longr.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
     // longest row; and what trip_gs compares between A and crs_U before it lets one pass over A stand in for the pass
     // over U: count, column sum and an order-independent hash of the value bits of the entries right of the diagonal
     its_host::row_stats(n_rows, row_ptr, col, val, which != ITS_MAT_L, &A.max_row_len, &A.n_upper, &A.upper_col_sum, &A.upper_val_xor);

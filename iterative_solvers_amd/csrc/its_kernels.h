@@ -88,6 +88,13 @@ struct CsrDev {
     int4 *blk_desc = nullptr;                 // {first row, rows, first nnz, end nnz} per row block
     int n_blocks_big = 0;
     int4 *blk_desc_big = nullptr;             // same with blocks of up to SPMV_NNZ_BIG entries (rows <= 8 entries only)
+    // irregular matrices without a panel image: the rows that do not fit a row block (> SPMV_NNZ_MAX entries: a block of
+    // their own, walked chunk by chunk by ONE lane between workgroup barriers) are taken out of the plan — blk_desc_short is
+    // blk_desc without those blocks — and get a wave each in a second launch (spmv_long_kernel), longest first
+    int4 *blk_desc_short = nullptr;
+    int n_blocks_short = 0;
+    int *irr_long_rows = nullptr;
+    int irr_n_long = 0;
     // vector-CSR plan
     int lanes_per_row = 0;
     int max_row_len = 0;                      // longest row: > IRR_ROW_LEN selects the irregular-row exact kernel
@@ -147,6 +154,8 @@ bool spmv_ell_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);
 struct SweepEll { double *val = nullptr; uint32_t *idx = nullptr; int w = 0, blocks = 0, kind = 0, lo = 0, cnt = 0, pb = 0; };
 int ell_choose_period(const int *dict, int n_off);    // row blocks per period of the ELL work map, 0 = none (its_ell.hip)
 void launch_sweep_ell_view(const CsrDev &L, const SweepEll &v, double *x, const double *rhs, const double *D, hipStream_t s);
+// the wave-per-row launch for a list of long rows (its_panel.hip); partial sums are ADDED to the ones a launch before it wrote
+void launch_spmv_long(const CsrDev &A, const int *rows, int n_long, const SpmvArgs &a, int epilogue, hipStream_t s);
 bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);     // its_panel.hip
 void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 int panel_tune(const char *name, int value);             // "spmv_panel", "spmv_panel_min_cols", "spmv_panel_log2pw", "spmv_panel_grid"

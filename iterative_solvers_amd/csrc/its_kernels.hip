@@ -784,6 +784,7 @@ static int g_spmv_valdict = env_int("ITS_SPMV_VALDICT", 0);     // opt-in: 1-byt
 static int g_spmv_vd_grid = env_int("ITS_SPMV_VD_GRID", 768);   // its grid (3 workgroups per CU measured best)
 static int g_spmv_irr = env_int("ITS_SPMV_IRR", 1);             // 0 = never use the irregular-row kernel
 static int g_spmv_irr_grid = env_int("ITS_SPMV_IRR_GRID", 1280);
+static int g_spmv_irr_split = env_int("ITS_SPMV_IRR_SPLIT", 1);     // rows beyond a row block on the wave-per-row launch
 static int g_spmv_irr_len = env_int("ITS_SPMV_IRR_LEN", IRR_ROW_LEN);   // longest row above which it is used
 static int g_spmv_bigplan = env_int("ITS_SPMV_BIGPLAN", 1);     // 0 = spmv_stream4_kernel on the ordinary plan too
 // the opt-in value-dictionary stream (2 bytes per nonzero) moves fewer bytes than the ELL image: it keeps its kernel
@@ -793,6 +794,7 @@ int spmv_tune(const char *name, int value)
     if (!strcmp(name, "spmv_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_grid = value; return 0; }
     if (!strcmp(name, "spmv_map")) { if (value < 0 || value > 1) return -1; g_spmv_map = value; return 0; }
     if (!strcmp(name, "spmv_variant")) { if (value != 2 && value != 4 && value != 5) return -1; g_spmv_variant = value; return 0; }
+    if (!strcmp(name, "spmv_irr_split")) { if (value < 0 || value > 1) return -1; g_spmv_irr_split = value; return 0; }
     if (!strcmp(name, "spmv_idx")) { if (value < 0 || value > 1) return -1; g_spmv_idx = value; return 0; }
     if (!strcmp(name, "spmv_valdict")) { if (value < 0 || value > 1) return -1; g_spmv_valdict = value; return 0; }
     if (!strcmp(name, "spmv_irr")) { if (value < 0 || value > 1) return -1; g_spmv_irr = value; return 0; }
@@ -941,6 +943,15 @@ void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
 {
     if (spmv_ell_eligible(A, a_in, epi)) { launch_spmv_ell(A, a_in, epi, s); return; }
     if (spmv_panel_eligible(A, a_in, epi)) { launch_spmv_panel(A, a_in, epi, s); return; }
+    // a row that does not fit a row block is walked by one lane, chunk by chunk between workgroup barriers: 16 ns per
+    // entry, and a 6000-entry hub row IS the product of a 20 000-row power-law matrix (0.105 ms).  Such rows go to the
+    // wave-per-row launch instead (spmv_long_kernel), the plan without them to the kernel below.
+    if (g_spmv_irr_split && A.irr_n_long > 0 && epi != EPI_SWEEP && a_in.row_end < 0) {
+        SpmvArgs a = a_in;
+        launch_spmv_exact_desc(A, A.blk_desc_short, A.n_blocks_short, a, epi, 0, s);
+        launch_spmv_long(A, A.irr_long_rows, A.irr_n_long, a, epi, s);
+        return;
+    }
     if (spmv_exact_takes_big_plan(A, a_in, epi)) launch_spmv_exact_desc(A, A.blk_desc_big, A.n_blocks_big, a_in, epi, 0, s);
     else launch_spmv_exact_desc(A, A.blk_desc, A.n_blocks, a_in, epi, 0, s);
 }

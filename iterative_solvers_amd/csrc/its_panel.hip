@@ -443,7 +443,8 @@ bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epi)
 {
     (void)a;
     return g_pan_on && A.pan_key != nullptr &&
-           (epi == EPI_STORE || epi == EPI_RESIDUAL || epi == EPI_JACOBI_REF || epi == EPI_JACOBI_FUSED || epi == EPI_GS_RHS || epi == EPI_GS_FUSED);
+           (epi == EPI_STORE || epi == EPI_RESIDUAL || epi == EPI_JACOBI_SHIPPED || epi == EPI_JACOBI_REF || epi == EPI_JACOBI_FUSED ||
+            epi == EPI_GS_RHS || epi == EPI_GS_FUSED);
 }
 
 void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t s)
@@ -462,6 +463,7 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
     switch (epi) {
     case EPI_STORE: if (a.dotv) ITS_LAUNCHP(EPI_STORE, true); else ITS_LAUNCHP(EPI_STORE, false); break;
     case EPI_RESIDUAL: ITS_LAUNCHP(EPI_RESIDUAL, false); break;
+    case EPI_JACOBI_SHIPPED: ITS_LAUNCHP(EPI_JACOBI_SHIPPED, false); break;
     case EPI_JACOBI_REF: ITS_LAUNCHP(EPI_JACOBI_REF, false); break;
     case EPI_GS_RHS: ITS_LAUNCHP(EPI_GS_RHS, false); break;
     case EPI_GS_FUSED: ITS_LAUNCHP(EPI_GS_FUSED, false); break;
@@ -470,22 +472,27 @@ void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream
 #undef ITS_LAUNCHP
     // the rows left out of the image: one wave each, partial sums added to the ones above (its grid never exceeds the
     // panel kernel's zero-filled ITS_NPART slots)
-    if (A.pan_n_long > 0) {
-        int gl = (A.pan_n_long + 3) / 4;
-        if (gl > ITS_NPART) gl = ITS_NPART;
-        dim3 g2(gl);
+    launch_spmv_long(A, A.pan_long_rows, A.pan_n_long, a, epi, s);
+}
+
+void launch_spmv_long(const CsrDev &A, const int *rows, int n_long, const SpmvArgs &a, int epi, hipStream_t s)
+{
+    if (n_long <= 0) return;
+    int gl = (n_long + 3) / 4;
+    if (gl > ITS_NPART) gl = ITS_NPART;
+    dim3 g2(gl), b(ITS_BLOCK);
 #define ITS_LAUNCHL(E, D) \
-    hipLaunchKernelGGL((spmv_long_kernel<E, D>), g2, b, 0, s, A.row_ptr, A.col, A.val, A.pan_long_rows, A.pan_n_long, a)
-        switch (epi) {
-        case EPI_STORE: if (a.dotv) ITS_LAUNCHL(EPI_STORE, true); else ITS_LAUNCHL(EPI_STORE, false); break;
-        case EPI_RESIDUAL: ITS_LAUNCHL(EPI_RESIDUAL, false); break;
-        case EPI_JACOBI_REF: ITS_LAUNCHL(EPI_JACOBI_REF, false); break;
-        case EPI_GS_RHS: ITS_LAUNCHL(EPI_GS_RHS, false); break;
-        case EPI_GS_FUSED: ITS_LAUNCHL(EPI_GS_FUSED, false); break;
-        default: ITS_LAUNCHL(EPI_JACOBI_FUSED, false); break;
-        }
-#undef ITS_LAUNCHL
+    hipLaunchKernelGGL((spmv_long_kernel<E, D>), g2, b, 0, s, A.row_ptr, A.col, A.val, rows, n_long, a)
+    switch (epi) {
+    case EPI_STORE: if (a.dotv) ITS_LAUNCHL(EPI_STORE, true); else ITS_LAUNCHL(EPI_STORE, false); break;
+    case EPI_RESIDUAL: ITS_LAUNCHL(EPI_RESIDUAL, false); break;
+    case EPI_JACOBI_SHIPPED: ITS_LAUNCHL(EPI_JACOBI_SHIPPED, false); break;
+    case EPI_JACOBI_REF: ITS_LAUNCHL(EPI_JACOBI_REF, false); break;
+    case EPI_GS_RHS: ITS_LAUNCHL(EPI_GS_RHS, false); break;
+    case EPI_GS_FUSED: ITS_LAUNCHL(EPI_GS_FUSED, false); break;
+    default: ITS_LAUNCHL(EPI_JACOBI_FUSED, false); break;
     }
+#undef ITS_LAUNCHL
 }
 
 }  // namespace its
