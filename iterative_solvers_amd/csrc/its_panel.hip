@@ -328,6 +328,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int LONG_LPL = 8;                         // entries per lane per chunk
 constexpr int LONG_CHUNK = LONG_LPL * ITS_WAVE;     // 512 entries staged per trip
+#ifndef ITS_LONG_WALK
+#define ITS_LONG_WALK 16
+#endif
+constexpr int LONG_WALK = ITS_LONG_WALK;            // entries per batch of the walk
 
 // The walk is one serial chain executed by a whole wave, so every instruction on it costs the SIMD a full issue: what an
 // epilogue leaves out of its chain (the diagonal, or everything left of it) is therefore decided while STAGING, in
@@ -386,24 +390,22 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const int ne = min(LONG_CHUNK, rj1 - c0);
             {
-                double2 pa[8], pb[8];
-#define LONG_RD(S, qv) _Pragma("unroll") for (int u = 0; u < 8; ++u) S[u] = strip[(qv) + u];
-#define LONG_FMA(S, cnt) _Pragma("unroll") for (int u = 0; u < 8; ++u) if (u < (cnt)) acc1 = fma(S[u].x, S[u].y, acc1);
+                // The walk: batches of LONG_WALK entries — all their LDS reads go out, the multiply-adds follow them in as they
+                // arrive (one read latency per batch, then the chain's own 8 cycles per entry).  (Two alternating sets of
+                // 8 with the next set read during the current one's multiply-adds compiled into 16 register copies per
+                // trip and waits on reads just issued: 30 cycles per entry.)
+#define LONG_RD(S, N, qv) _Pragma("unroll") for (int u = 0; u < (N); ++u) S[u] = strip[(qv) + u];
+#define LONG_FMA(S, N, cnt) _Pragma("unroll") for (int u = 0; u < (N); ++u) if (u < (cnt)) acc1 = fma(S[u].x, S[u].y, acc1);
                 int q = 0;
-                LONG_RD(pa, 0)
-                for (; q + 16 <= ne; q += 16) {
-                    LONG_RD(pb, q + 8)
-                    LONG_FMA(pa, 8)
-                    LONG_RD(pa, q + 16)
-                    LONG_FMA(pb, 8)
+                for (; q + LONG_WALK <= ne; q += LONG_WALK) {
+                    double2 pw[LONG_WALK];
+                    LONG_RD(pw, LONG_WALK, q)
+                    LONG_FMA(pw, LONG_WALK, LONG_WALK)
                 }
-                if (q + 8 <= ne) {
-                    LONG_RD(pb, q + 8)
-                    LONG_FMA(pa, 8)
-                    q += 8;
-                    LONG_FMA(pb, ne - q)
-                } else {
-                    LONG_FMA(pa, ne - q)
+                for (; q < ne; q += 8) {
+                    double2 p8[8];
+                    LONG_RD(p8, 8, q)                  // (the strip is 8 entries longer than a chunk)
+                    LONG_FMA(p8, 8, ne - q)
                 }
 #undef LONG_RD
 #undef LONG_FMA
