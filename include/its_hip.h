@@ -96,7 +96,8 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *   "gmres_persist" 1 (default) = the Gram-Schmidt sweep of a GMRES trip (gmres.hpp:269-389: every h_j = w . v_j,
  *                  w -= h_j v_j, ||w||, v_{k+1}) is ONE persistent launch that keeps w in registers and reads each
  *                  basis vector once (its_mgs.hip), when the run is on one GPU, uses modified Gram-Schmidt and the
- *                  vectors have between "gmres_persist_min_n" (default 2^19) and 12 * 960 * CUs (2.9 M) entries;
+ *                  vectors have between "gmres_persist_min_n" (default 1) and 12 * 960 * CUs (2.9 M) entries; the grid is
+ *                  one workgroup per CU for long vectors and as few as 8 for short ones;
  *                  0 = one launch per basis vector.  Same operations per element; the dot products are summed in
  *                  another fixed order (H agrees to rounding, not bit for bit).  A launch whose workgroups cannot all
  *                  be resident (another process on the GPU) gives up after 20 ms and the trip is repeated the other way.

@@ -1196,7 +1196,10 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     if (rc) return rc;
     if (h->precond == ITS_PRECOND_GS) { if ((rc = sweep(h, w, w))) return rc; }   // gmres.hpp:251
     // the Hessenberg column is written straight into pinned host memory (region pin_h, m + 2 doubles), or copied
-    const bool use_copy = readback_mode() == 2;
+    // (the persistent Gram-Schmidt launch always writes the column to pinned memory — a launch that gave up is recognised
+    // by the word it left armed; in read-back mode 2 the host then synchronizes before it reads, which is what that mode
+    // is for, so every mode runs the same kernels and returns the same bits)
+    const bool use_copy = readback_mode() == 2 && h->mgs_grid <= 0;
     const bool hcol_pinned = !use_copy;
     double *hcol_out = hcol_pinned ? h->pinned + h->pin_h : h->hcol_dev;
     // every entry of the column is armed, not only the last one: the entries come from k + 2 different kernels, and that

@@ -50,8 +50,9 @@ struct its_handle {
     // communication-reducing variants (its_krylov_cr.hip), opt-in: "cg_variant" 1 = pipelined CG, "gmres_ortho" 1 = CGS-2
     int cg_variant = 0, gmres_ortho = 0;
     // persistent modified Gram-Schmidt (its_mgs.hip): option "gmres_persist" (1), for vectors of at least
-    // "gmres_persist_min_n" doubles that fit the registers of one resident grid; mgs_grid == 0: per-step kernels
-    int gmres_persist = 1, gmres_persist_min_n = 1 << 19;
+    // "gmres_persist_min_n" doubles (default 1: every length) that fit the registers of one resident grid;
+    // mgs_grid == 0: per-step kernels
+    int gmres_persist = 1, gmres_persist_min_n = 1;
     unsigned long long *mgs_slots = nullptr;
     int mgs_grid = 0, mgs_fallbacks = 0, mgs_parity = 0;
     int mgs_inject_fail = 0;              // option "gmres_persist_inject_fail" (tests): launches that give up on purpose

@@ -4,8 +4,9 @@ C ABI: one launch per trip that keeps w in registers instead of one launch per b
 Same operations per element as the per-step kernels; the dot products are summed in another fixed order, so the
 Hessenberg entries agree to rounding, not bit for bit.  Bar: the one every GMRES test has (test_gpu_solvers.py:
 history within 1e-10 relative / the oracle's own reduction-order noise envelope, count +-1 %, x_star 1e-9).
-"gmres_persist_min_n" = 1 forces the launch onto the small matrices the oracle finishes in seconds; at 128^3 it is
-the default path (test_gpu_fullsize.py).
+The launch is the default for every vector length up to 2.9 M entries (the grid shrinks with the vectors: 8 workgroups
+for the small matrices the oracle finishes in seconds, one per CU at 128^3, test_gpu_fullsize.py); "gmres_persist" 0 or
+a larger "gmres_persist_min_n" selects one launch per basis vector.
 """
 import numpy as np
 import pytest
@@ -54,17 +55,19 @@ def _solve(rp, col, val, restart, trips, options):
 @pytest.mark.parametrize("gen,restart", [("lap3d_40", 20), ("cd27_33", 12), ("lap2d_301", 25)])
 def test_persistent_launch_agrees_with_per_step_kernels(gen, restart):
     """Both forms of the sweep on the same matrix (n = 64 000, 35 937 — odd —, 90 601 — odd): histories agree to
-    1e-11 relative over 2.5 restart cycles, x_star to 1e-11; the default threshold leaves vectors this short on the
-    per-step kernels."""
+    1e-11 relative over 2.5 restart cycles, x_star to 1e-11; the default is the persistent launch, and a threshold
+    above the vector length ("gmres_persist_min_n") is the per-step kernels."""
     rp, col, val = {"lap3d_40": lambda: matgen.laplace3d_7pt(40), "cd27_33": lambda: matgen.convdiff3d_27pt(33),
                     "lap2d_301": lambda: matgen.laplace2d_5pt(301)}[gen]()
     trips = restart * 5 // 2
     h1, x1, i1 = _solve(rp, col, val, restart, trips, FORCE)
     h0, x0, i0 = _solve(rp, col, val, restart, trips, {"gmres_persist": 0})
     hd, xd, idf = _solve(rp, col, val, restart, trips, {})
-    assert i1["persist_grid"] > 0 and i1["fallbacks"] == 0 and i0["persist_grid"] == 0 and idf["persist_grid"] == 0
+    hm, xm, im = _solve(rp, col, val, restart, trips, {"gmres_persist_min_n": 10**9})
+    assert i1["persist_grid"] > 0 and i1["fallbacks"] == 0 and i0["persist_grid"] == 0 and im["persist_grid"] == 0
+    assert idf["persist_grid"] == i1["persist_grid"] and idf["persist_grid"] % 8 == 0
     assert len(h1) == len(h0) > restart
-    assert np.array_equal(h0, hd) and np.array_equal(x0, xd)
+    assert np.array_equal(h1, hd) and np.array_equal(x1, xd) and np.array_equal(h0, hm) and np.array_equal(x0, xm)
     assert np.max(np.abs(h1 - h0) / h0) <= 1e-11, np.max(np.abs(h1 - h0) / h0)
     assert np.max(np.abs(x1 - x0)) <= 1e-11 * np.max(np.abs(x0))
 

@@ -295,6 +295,14 @@ int main(int argc, char **argv)
     run(mgs_persist_kernel<512, 4>, 512, 4, cus * 2, "persist<512,4> x2");
     run(mgs_persist2_kernel<15, 5, 0>, 960, 5, cus, "persist2<15,5> all-to-all", 64);
     run(mgs_persist2_kernel<15, 5, 1>, 960, 5, cus, "persist2<15,5> two-level", 64);
+    if (n <= 131072) {
+        // few workgroups: is the grid-wide sum cheaper with fewer participants (short vectors)?
+        run(mgs_persist2_kernel<15, 5, 1, 0, 4>, 960, 5, 8, "persist2 G=8 nb4", 64);
+        run(mgs_persist2_kernel<15, 5, 1, 0, 8>, 960, 5, 16, "persist2 G=16 nb8", 64);
+        run(mgs_persist2_kernel<15, 2, 1, 0, 16>, 960, 2, 32, "persist2 G=32 nb16", 64);
+        run(mgs_persist2_kernel<15, 1, 1, 0, 16>, 960, 1, 64, "persist2 G=64 nb16", 64);
+        run(mgs_persist2_kernel<15, 1, 1, 0, 16>, 960, 1, 128, "persist2 G=128 nb16", 64);
+    }
     run(mgs_persist2_kernel<15, 5, 3, 0, 8>, 960, 5, cus, "persist2<15,5> all-to-all r8", 64);
     run(mgs_persist2_kernel<15, 5, 3, 0, 16>, 960, 5, cus, "persist2<15,5> all-to-all r16", 64);
     run(mgs_persist2_kernel<15, 5, 3, 0, 32>, 960, 5, cus, "persist2<15,5> all-to-all r32", 64);
