@@ -979,7 +979,9 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         dfree(h->mgs_slots); h->mgs_grid = 0; h->mgs_fallbacks = 0;
         if (h->gmres_persist && h->gmres_ortho == 0 && !its_dist_active(h) && n >= h->gmres_persist_min_n) {
             h->mgs_grid = mgs_persist_grid(n, h->device);
-            if (h->mgs_grid > 0 && dalloc(h, &h->mgs_slots, mgs_persist_slot_words(m, h->mgs_grid))) return ITS_EHIP;
+            // (its slots grow with restart length x workgroups: beyond 256 MB, or if they cannot be had, the per-step kernels)
+            if (h->mgs_grid > 0 && mgs_persist_slot_words(m, h->mgs_grid) > ((size_t)256 << 20) / sizeof(unsigned long long)) h->mgs_grid = 0;
+            if (h->mgs_grid > 0 && dalloc(h, &h->mgs_slots, mgs_persist_slot_words(m, h->mgs_grid))) { h->mgs_grid = 0; h->err.clear(); (void)hipGetLastError(); }
             if (h->mgs_grid > 0) HIPCHK(h, mgs_persist_reset(h->mgs_slots, m, h->mgs_grid, h->stream));
         }
         if (getenv("ITS_DEBUG_GMRES")) fprintf(stderr, "its_solver_setup(GMRES): Gram-Schmidt %s (%d workgroups), n = %d, restart %d\n", h->mgs_grid > 0 ? "as one persistent launch per trip" : "as one launch per basis vector", h->mgs_grid, n, m);
