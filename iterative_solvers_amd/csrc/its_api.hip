@@ -1153,11 +1153,13 @@ static int trip_gs(its_handle *h, double *res_out)
     // compared): the residual pass over A then also yields b - U x_new for the next trip (EPI_GS_FUSED)
     // (not for matrices on the irregular-row kernel: its one-lane-per-row walk out of LDS is issue-bound, and the
     // per-entry column test of the second chain costs more there than the separate pass over U: 2.7 vs 2.3 ms on
-    // the power-law matrix in multicolour order; with the panel image of A the fused pass wins again)
+    // the power-law matrix in multicolour order; with the panel image of A the fused pass wins again, and so it does where
+    // the hub rows are on the wave-per-row launch, whose second chain is free: its_solve -gs, 200 000-row power-law matrix,
+    // 0.63 -> 0.56 ms per trip)
     const CsrDev &Am = h->mat[ITS_MAT_A], &Um = h->mat[ITS_MAT_U];
     const bool fused = h->fused_residual && Um.nnz == Am.n_upper && Um.n_upper == Um.nnz &&
                        Um.upper_col_sum == Am.upper_col_sum && Um.upper_val_xor == Am.upper_val_xor &&
-                       (Am.max_row_len <= IRR_ROW_LEN || spmv_panel_eligible(Am, u, EPI_GS_FUSED)) && !its_dist_active(h);
+                       (Am.max_row_len <= IRR_ROW_LEN || spmv_panel_eligible(Am, u, EPI_GS_FUSED) || Am.irr_n_long > 0) && !its_dist_active(h);
     // first sweep level without entries in L (the first colour): its rows' next iterate is (b - U x) / D, which the fused
     // pass can store itself (ELL kernels) — into x_b, because other rows of that pass still read the current x
     const int lo0 = h->n_levels >= 2 ? h->level_empty_lo[0] : -1, hi0 = lo0 >= 0 ? lo0 + (h->level_ptr[1] - h->level_ptr[0]) : -1;
