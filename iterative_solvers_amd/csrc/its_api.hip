@@ -841,7 +841,7 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
         HIPCHK(h, hipMemcpy(h->level_ptr_dev, h->level_ptr.data(), ((size_t)nl + 1) * sizeof(int), hipMemcpyHostToDevice));
         auto small = [&](int l) {
             return h->level_desc_count[l] == 0 && h->level_empty_lo[l] < 0 && !h->level_ell[l].val &&
-                   h->level_ptr[l + 1] - h->level_ptr[l] <= sweep_run_rows();
+                   h->level_ptr[l + 1] - h->level_ptr[l] <= sweep_run_rows(h->sw_w);
         };
         for (int l = 0; l < nl;) {
             if (!small(l)) { ++l; continue; }

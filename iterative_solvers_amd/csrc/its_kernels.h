@@ -239,11 +239,11 @@ constexpr int SWEEP_SHORT = 16;            // rows of L up to this length take o
 void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int n_short, double *x,
                         const double *rhs, const double *D, hipStream_t s);
 // level-ordered copy of L (rows of at most SWEEP_ELL_W entries): slot-major (col, val) + diagonal per list position
-constexpr int SWEEP_ELL_W = 8;
+constexpr int SWEEP_ELL_W = 16;           // (rows of L of a 27-point stencil have up to 13 entries)
 void launch_sweep_ell_build(int n, int W, const int *rows, const CsrDev &L, const double *D, int *sw_col, double *sw_val,
                             double *sw_D, hipStream_t s);
-// a run of consecutive levels of at most sweep_run_rows() list positions each, in one launch of one workgroup
-int sweep_run_rows();
+// a run of consecutive levels of at most sweep_run_rows(W) list positions each, in one launch of one workgroup
+int sweep_run_rows(int W);
 void launch_sweep_ell_run(int n, int W, int l0, int l1, const int *level_ptr_dev, const int *rows, const int *sw_col,
                           const double *sw_val, const double *sw_D, double *x, const double *rhs, hipStream_t s);
 void launch_sweep_ell_level(int n, int W, int p0, int p1, const int *rows, const int *sw_col, const double *sw_val,

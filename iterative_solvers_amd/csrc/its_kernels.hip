@@ -1731,21 +1731,30 @@ void launch_sweep_ell_level(int n, int W, int p0, int p1, const int *rows, const
     case 5: ITS_LAUNCHSW(5); break;
     case 6: ITS_LAUNCHSW(6); break;
     case 7: ITS_LAUNCHSW(7); break;
-    default: ITS_LAUNCHSW(8); break;
+    case 8: ITS_LAUNCHSW(8); break;
+    case 9: ITS_LAUNCHSW(9); break;
+    case 10: ITS_LAUNCHSW(10); break;
+    case 11: ITS_LAUNCHSW(11); break;
+    case 12: ITS_LAUNCHSW(12); break;
+    case 13: ITS_LAUNCHSW(13); break;
+    case 14: ITS_LAUNCHSW(14); break;
+    case 15: ITS_LAUNCHSW(15); break;
+    default: ITS_LAUNCHSW(16); break;
     }
 #undef ITS_LAUNCHSW
 }
 
-// A RUN of consecutive small levels (each of at most SWEEP_RUN_ROWS list positions: the natural-order sweep of a 2-D
+// A RUN of consecutive small levels (each of at most sweep_run_rows(W) list positions: the natural-order sweep of a 2-D
 // stencil has nothing else — 511 levels of <= 256 rows on a 256 x 256 grid — and a 3-D one starts and ends with them) in
 // ONE launch of ONE workgroup: a lane owns one list position per level, the levels are separated by a workgroup barrier
 // instead of a kernel boundary (all waves of a workgroup share the CU's L1, so a barrier makes the level's x visible),
 // and the next level's row, diagonal, right-hand side and entries — which do not depend on x — are loaded while the
 // current level's gathers are in flight: one dependent round trip per level.  A launch per level cost 3.2 us
 // (its_solve -gs on the 256 x 256 Laplacian: 1.62 ms per trip).  Same entries in the same order: bit-identical.
-constexpr int SWEEP_RUN_ROWS = 1024;
-template <int W>
-__global__ __launch_bounds__(SWEEP_RUN_ROWS) void sweep_ell_run_kernel(
+// (1024 lanes for copies of up to 8 entries per row, 512 for wider ones: 3 W registers for the level in hand and as many
+// for the next one)
+template <int W, int NT>
+__global__ __launch_bounds__(NT) void sweep_ell_run_kernel(
     int n, int l0, int l1, const int *__restrict__ lptr, const int *__restrict__ rows, const int *__restrict__ sw_col,
     const double *__restrict__ sw_val, const double *__restrict__ sw_D, double *x, const double *rhs)
 {
@@ -1801,21 +1810,29 @@ void launch_sweep_ell_run(int n, int W, int l0, int l1, const int *level_ptr_dev
                           const double *sw_val, const double *sw_D, double *x, const double *rhs, hipStream_t s)
 {
     if (l1 <= l0) return;
-    dim3 g(1), b(SWEEP_RUN_ROWS);
-#define ITS_LAUNCHSR(WW) hipLaunchKernelGGL((sweep_ell_run_kernel<WW>), g, b, 0, s, n, l0, l1, level_ptr_dev, rows, sw_col, sw_val, sw_D, x, rhs)
+    dim3 g(1);
+#define ITS_LAUNCHSR(WW, NT) hipLaunchKernelGGL((sweep_ell_run_kernel<WW, NT>), g, dim3(NT), 0, s, n, l0, l1, level_ptr_dev, rows, sw_col, sw_val, sw_D, x, rhs)
     switch (W) {
-    case 1: ITS_LAUNCHSR(1); break;
-    case 2: ITS_LAUNCHSR(2); break;
-    case 3: ITS_LAUNCHSR(3); break;
-    case 4: ITS_LAUNCHSR(4); break;
-    case 5: ITS_LAUNCHSR(5); break;
-    case 6: ITS_LAUNCHSR(6); break;
-    case 7: ITS_LAUNCHSR(7); break;
-    default: ITS_LAUNCHSR(8); break;
+    case 1: ITS_LAUNCHSR(1, 1024); break;
+    case 2: ITS_LAUNCHSR(2, 1024); break;
+    case 3: ITS_LAUNCHSR(3, 1024); break;
+    case 4: ITS_LAUNCHSR(4, 1024); break;
+    case 5: ITS_LAUNCHSR(5, 1024); break;
+    case 6: ITS_LAUNCHSR(6, 1024); break;
+    case 7: ITS_LAUNCHSR(7, 1024); break;
+    case 8: ITS_LAUNCHSR(8, 1024); break;
+    case 9: ITS_LAUNCHSR(9, 512); break;
+    case 10: ITS_LAUNCHSR(10, 512); break;
+    case 11: ITS_LAUNCHSR(11, 512); break;
+    case 12: ITS_LAUNCHSR(12, 512); break;
+    case 13: ITS_LAUNCHSR(13, 512); break;
+    case 14: ITS_LAUNCHSR(14, 512); break;
+    case 15: ITS_LAUNCHSR(15, 512); break;
+    default: ITS_LAUNCHSR(16, 512); break;
     }
 #undef ITS_LAUNCHSR
 }
-int sweep_run_rows() { return SWEEP_RUN_ROWS; }
+int sweep_run_rows(int W) { return W <= 8 ? 1024 : 512; }
 
 void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int n_short, double *x,
                         const double *rhs, const double *D, hipStream_t s)
