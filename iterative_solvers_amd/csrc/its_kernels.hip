@@ -1566,14 +1566,15 @@ void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t
 // the row length; the level's long rows run side by side.
 constexpr int SWEEP_LPL = 8;                        // entries of a long row per lane per chunk
 constexpr int SWEEP_CHUNK = SWEEP_LPL * ITS_WAVE;   // entries of a long row staged per trip
+constexpr int SWEEP_MERGE_ROWS = 1 << 18;           // levels up to this size with both kinds of rows go out as one launch
 
-__global__ __launch_bounds__(ITS_BLOCK) void sweep_short_kernel(
-    const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+__device__ __forceinline__ void sweep_short_rows(
+    int bid, int nb, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
     const int *__restrict__ rows, int n_short, double *x, const double *__restrict__ rhs, const double *__restrict__ D)
 {
     {
-        const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
-        for (int64_t k = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x; k < n_short; k += nth) {
+        const int64_t nth = (int64_t)nb * ITS_BLOCK;
+        for (int64_t k = (int64_t)bid * ITS_BLOCK + threadIdx.x; k < n_short; k += nth) {
             const int row = rows ? rows[k] : (int)k;
             const int j0 = rp[row], j1 = rp[row + 1];
             double s = 0.0;
@@ -1595,21 +1596,24 @@ __global__ __launch_bounds__(ITS_BLOCK) void sweep_short_kernel(
     }
 }
 
-// (a kernel of its own: its staging registers would halve the occupancy of the latency-bound short rows)
-__global__ __launch_bounds__(ITS_BLOCK) void sweep_long_kernel(
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_short_kernel(
     const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
-    const int *__restrict__ rows, int n_level_rows, int n_short, double *x,
+    const int *__restrict__ rows, int n_short, double *x, const double *__restrict__ rhs, const double *__restrict__ D)
+{ sweep_short_rows(blockIdx.x, gridDim.x, rp, col, val, rows, n_short, x, rhs, D); }
+
+__device__ __forceinline__ void sweep_long_rows(
+    int bid, int nb, double2 (*s_vx)[SWEEP_CHUNK + 8], const int *__restrict__ rp, const int *__restrict__ col,
+    const double *__restrict__ val, const int *__restrict__ rows, int n_level_rows, int n_short, double *x,
     const double *__restrict__ rhs, const double *__restrict__ D)
 {
-    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][SWEEP_CHUNK + 8];   // + 8: the chain reads one batch ahead
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     // Long rows.  The chain is serial by definition (one fused multiply-add per entry, in CRS order), so the
     // level cannot finish before its longest row has walked its entries: everything else is kept off that path.
     //   loads    two chunks ahead: col/val of chunk c+2 and the x gathers of chunk c+1 (whose columns arrived a
     //            trip ago) are in flight while chunk c is walked, so no trip waits for a memory round trip
     //   chain    reads LDS in batches of 16 entries
-    const int64_t wstride = (int64_t)gridDim.x * (ITS_BLOCK / ITS_WAVE);
-    for (int64_t k = n_short + (int64_t)blockIdx.x * (ITS_BLOCK / ITS_WAVE) + w; k < n_level_rows; k += wstride) {
+    const int64_t wstride = (int64_t)nb * (ITS_BLOCK / ITS_WAVE);
+    for (int64_t k = n_short + (int64_t)bid * (ITS_BLOCK / ITS_WAVE) + w; k < n_level_rows; k += wstride) {
         const int row = rows[k];
         const int rj0 = rp[row], rj1 = rp[row + 1];
         double acc = 0.0;
@@ -1662,6 +1666,30 @@ __global__ __launch_bounds__(ITS_BLOCK) void sweep_long_kernel(
 #undef SWEEP_GATHER
         if (l == 0) x[row] = (rhs[row] - acc) / D[row];
     }
+}
+
+// (a kernel of its own for levels that only have long rows: its staging registers would halve the occupancy of the
+// latency-bound short rows of big levels)
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_long_kernel(
+    const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+    const int *__restrict__ rows, int n_level_rows, int n_short, double *x,
+    const double *__restrict__ rhs, const double *__restrict__ D)
+{
+    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][SWEEP_CHUNK + 8];   // + 8: the walk's last batch may read past the chunk
+    sweep_long_rows(blockIdx.x, gridDim.x, s_vx, rp, col, val, rows, n_level_rows, n_short, x, rhs, D);
+}
+
+// A level that has both kinds of rows and is small (a natural-order sweep of an irregular matrix: two dozen levels of a
+// few thousand rows, each with a handful of hub rows) as ONE launch: the first gl workgroups take the long rows — they
+// last longest — the others the short ones.  Two launches per level were 14 + 6 us on the 200 000-row power-law matrix.
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_level_kernel(
+    const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+    const int *__restrict__ rows, int n_level_rows, int n_short, int gl, double *x,
+    const double *__restrict__ rhs, const double *__restrict__ D)
+{
+    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][SWEEP_CHUNK + 8];
+    if ((int)blockIdx.x < gl) sweep_long_rows(blockIdx.x, gl, s_vx, rp, col, val, rows, n_level_rows, n_short, x, rhs, D);
+    else sweep_short_rows(blockIdx.x - gl, gridDim.x - gl, rp, col, val, rows, n_short, x, rhs, D);
 }
 
 // --------------------------------------------------------------------------------------
@@ -1845,6 +1873,11 @@ void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int 
     int gl = (n_long + 3) / 4;
     if (gl > 4 * ITS_NPART) gl = 4 * ITS_NPART;
     // rows of a level are independent, so the order of the two launches does not matter
+    if (gs > 0 && gl > 0 && n_level_rows <= SWEEP_MERGE_ROWS) {
+        hipLaunchKernelGGL(sweep_level_kernel, dim3(gl + gs), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val, rows, n_level_rows,
+                           n_short, gl, x, rhs, D);
+        return;
+    }
     if (gs > 0)
         hipLaunchKernelGGL(sweep_short_kernel, dim3(gs), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val, rows, n_short, x, rhs, D);
     if (gl > 0)
