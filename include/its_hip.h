@@ -139,9 +139,9 @@ int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precon
  *                  place in the image; 64: 1.05 ms, 128: 0.95, 192: 0.96, 256: 0.99 on the 10 M-row power-law matrix).
  *                  "spmv_panel_grid" workgroups (1024)
  *   "spmv_irr"     1 (default) = two-phase kernel when the longest row exceeds 32 entries
- *   "spmv_irr_split" 1 (default) = rows of such a matrix that do not fit a row block (> 1536 entries) leave the plan and get
- *                  a wave each in a second launch, longest first (as the rows outside a panel image do); 0 = one lane walks
- *                  them chunk by chunk inside the two-phase kernel
+ *   "spmv_irr_split" 1 (default) = rows of such a matrix with more than 256 entries (environment ITS_SPMV_SOLO_LEN, read at upload)
+ *                  leave the plan and get a wave each in a second launch, longest first (as the rows outside a panel image
+ *                  do); 0 = one lane walks them inside the two-phase kernel
  *   "spmv_variant" 4 (default) | 5 | 2, "spmv_grid", "spmv_irr_grid", "spmv_irr_len", "spmv_map" 0|1:
  *                  tuning knobs kept for A/B measurements (tools/spmv_ab.py) */
 int its_set_option(its_handle *h, const char *name, int value);

@@ -145,15 +145,18 @@ extern "C" int its_destroy(its_handle *h)
 // ---------------------------------------------------------------------------------------
 // host-side plans
 // ---------------------------------------------------------------------------------------
+// (solo_len > 0: a row of more than solo_len entries is a block of its own)
 static void build_stream_plan(int n, const int *rp, std::vector<int> &blk, int max_rows = ITS_BLOCK,
-                              int max_nnz = SPMV_NNZ_MAX)
+                              int max_nnz = SPMV_NNZ_MAX, int solo_len = 0)
 {
     blk.clear(); blk.push_back(0);
     int rs = 0;
     while (rs < n) {
         int re = rs + 1;                                     // a block always takes one row
         const int64_t a0 = rp[rs];
-        while (re < n && re - rs < max_rows && (int64_t)rp[re + 1] - a0 <= max_nnz) ++re;
+        const bool solo = solo_len > 0 && rp[rs + 1] - rp[rs] > solo_len;
+        while (!solo && re < n && re - rs < max_rows && (int64_t)rp[re + 1] - a0 <= max_nnz &&
+               !(solo_len > 0 && rp[re + 1] - rp[re] > solo_len)) ++re;
         blk.push_back(re);
         rs = re;
     }
@@ -335,13 +338,27 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         desc[i] = make_int4(blk[i], (blk[i + 1] - blk[i]) | (std::min(longest[i], 0x7fff) << 16), row_ptr[blk[i]], row_ptr[blk[i + 1]]);
     if (dalloc(h, &A.blk_desc, desc.size())) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.blk_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
-    // rows that do not fit a row block: out of the plan, onto the wave-per-row launch (its_kernels.h, CsrDev::blk_desc_short)
+    // hub rows: out of the plan, onto the wave-per-row launch (its_kernels.h, CsrDev::blk_desc_short).  One lane of the
+    // irregular-row kernel walks a row at 16 ns per entry while its workgroup waits, a wave of spmv_long_kernel at 7-9 ns:
+    // the cut is not the row block's capacity but SPMV_SOLO_LEN entries (200 000-row power-law matrix, the launch over the
+    // plan: 34 us with the rows of up to 1536 entries in it)
     {
         std::vector<int4> shortd;
         std::vector<int> longr;
-        for (int i = 0; i < A.n_blocks; ++i) {
-            if (desc[i].w - desc[i].z > SPMV_NNZ_MAX && (desc[i].y & 0xffff) == 1) longr.push_back(desc[i].x);
-            else shortd.push_back(desc[i]);
+        static const int solo_len = []{ const char *e = getenv("ITS_SPMV_SOLO_LEN"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SPMV_SOLO_LEN; }();
+        bool any = false;
+        for (int i = 0; i < A.n_blocks && !any; ++i) any = (longest[i] > solo_len);
+        if (any) {
+            std::vector<int> blk2, longest2;
+            build_stream_plan(n_rows, row_ptr, blk2, ITS_BLOCK, SPMV_NNZ_MAX, solo_len);
+            const int nb2 = (int)blk2.size() - 1;
+            longest2.assign(std::max(nb2, 1), 0);
+            its_host::block_longest(nb2, blk2.data(), row_ptr, longest2.data());
+            for (int i = 0; i < nb2; ++i) {
+                if (longest2[i] > solo_len) longr.push_back(blk2[i]);      // (a block of one row by construction)
+                else shortd.push_back(make_int4(blk2[i], (blk2[i + 1] - blk2[i]) | (std::min(longest2[i], 0x7fff) << 16),
+                                                row_ptr[blk2[i]], row_ptr[blk2[i + 1]]));
+            }
         }
         if (!longr.empty() && !shortd.empty()) {
             std::sort(longr.begin(), longr.end(), [&](int r0, int r1) {

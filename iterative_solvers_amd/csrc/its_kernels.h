@@ -17,6 +17,7 @@ constexpr int SPMV_NNZ_MAX = 1536;        // (1536+8)*(8+4) B + row ptrs ≈ 19.
 // hold 2048 entries per trip, and with 256 full rows per block (7-pt: 1792 entries) it runs 3 % faster; the
 // four-per-CU kernel needs the smaller LDS footprint of SPMV_NNZ_MAX
 constexpr int SPMV_NNZ_BIG = 2040;
+constexpr int SPMV_SOLO_LEN = 256;        // rows longer than this leave the irregular-row plan for the wave-per-row launch
 // column-panel blocked image of large irregular matrices (its_panel.hip)
 constexpr int PAN_TR = 4096;              // rows per tile: their running sums live in LDS (32 KB)
 constexpr int PAN_CH = 256;               // entries per chunk (one per lane); a chunk never spans two panels

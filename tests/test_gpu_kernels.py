@@ -38,6 +38,8 @@ def test_spmv_generated(gpu_handle, name):
     (1, 3, 0, ()), (7, 0, 0, ()), (63, 5, 2, ()), (257, 9, 3, ()), (1000, 40, 7, ()),
     (3000, 12, 0, ((5, 1792), (6, 1793), (100, 9000), (2999, 4000))),   # rows at / past the LDS chunk size
     (70000, 6, 5, ((69999, 300),)),
+    # either side of SPMV_SOLO_LEN (256) and of the row block's capacity (1536), neighbours, first and last row
+    (5000, 10, 4, ((0, 257), (1, 256), (2, 1000), (3, 1536), (4, 1537), (2500, 600), (2501, 700), (4999, 258))),
 ])
 def test_spmv_ragged(gpu_handle, n, max_len, empty_every, long_rows):
     rp, col, val = random_crs(n, max_len, seed=n, empty_every=empty_every, long_rows=long_rows)

@@ -237,6 +237,37 @@ def test_one_matrix_pass_per_trip_is_bit_identical(flag, name, valdict):
     assert np.array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("flag,jacobi_mode", [("-j", 0), ("-j", 1), ("-gs", 0), ("-cg", 0)])
+def test_hub_rows_on_the_wave_per_row_launch_give_the_same_iterates(flag, jacobi_mode):
+    """Rows of more than SPMV_SOLO_LEN (256) entries leave the irregular-row plan for spmv_long_kernel (one wave per
+    row); option spmv_irr_split = 0 keeps them in the plan.  Every row's chain is the same in-order sum either way:
+    Jacobi / GS iterates bit-identical; the recorded norms are sums of per-workgroup partial sums, whose grouping follows
+    the plan (1e-13), and CG's scalars come from such sums (its x within 1e-12)."""
+    from iterative_solvers_amd import matgen
+    rp, col, val = matgen.powerlaw(20000)
+    n = len(rp) - 1
+    lens = np.diff(rp)
+    assert ((lens > 256) & (lens <= 1536)).sum() > 0 and lens.max() > 1536
+    out = []
+    for split in (1, 0):
+        args = S.Args(S.CLI_SOLVER[flag], S.LoopParams(max_iters=30, tol=1e-13), S.Flags(), "", "none")
+        sol = S.Solver(args.solver_type, device=0, jacobi_mode=jacobi_mode)
+        try:
+            sol.handle.set_option("spmv_irr_split", split)
+            _, r0_two = S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.zeros(n))
+            S.solve(args, sol)
+            out.append((args.normed_residuals[:args.loop_params.residual_count].copy(), sol.x_star.copy()))
+        finally:
+            sol.handle.set_option("spmv_irr_split", 1)
+            sol.handle.close()
+    assert len(out[0][0]) == len(out[1][0]) and len(out[0][0]) > 3
+    assert np.all(np.abs(out[0][0] - out[1][0]) <= 1e-13 * np.maximum(np.abs(out[1][0]), r0_two))   # (shipped Jacobi diverges here)
+    if flag == "-cg":
+        assert np.max(np.abs(out[0][1] - out[1][1])) <= 1e-12 * np.max(np.abs(out[1][1]))
+    else:
+        assert np.array_equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("gen", ["lap3d_32", "cd27_24", "pl_60000"])
 def test_multicolor_sweep_on_stream_kernels_is_bit_identical(gen):
     """A colour that is one contiguous range of >= 4096 rows is swept by the exact SpMV kernels with the sweep
