@@ -332,6 +332,18 @@ constexpr int LONG_CHUNK = LONG_LPL * ITS_WAVE;     // 512 entries staged per tr
 #define ITS_LONG_WALK 16
 #endif
 constexpr int LONG_WALK = ITS_LONG_WALK;            // entries per batch of the walk
+#ifndef ITS_LONG_PIPE
+#define ITS_LONG_PIPE 1
+#endif
+#ifndef ITS_LONG_PIPE_W
+#define ITS_LONG_PIPE_W 12
+#endif
+constexpr int LONG_PIPE_W = ITS_LONG_PIPE_W;        // entries per register set of the pipelined walk: two sets in flight must stay
+                                                    // countable by s_waitcnt's 4-bit LDS counter (16 per set: the chain waits for
+                                                    // reads just issued).  (Walking with only lanes 0 and 1 active: no faster — the LDS read costs the wave its 8 issue
+                                                    // cycles whatever the mask, and that, not latency, is what stands beside the chain's 8.)
+constexpr int LONG_PAD = 16;                        // the walk reads up to a batch past the chunk (never uses what it finds there)
+static_assert(LONG_PIPE_W <= LONG_PAD && LONG_WALK <= LONG_PAD, "strip pad");
 
 // The walk is one serial chain executed by a whole wave, so every instruction on it costs the SIMD a full issue: what an
 // epilogue leaves out of its chain (the diagonal, or everything left of it) is therefore decided while STAGING, in
@@ -346,8 +358,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
 {
     constexpr bool COLS = EpiKind<EPI>::needs_col;
     constexpr bool FUSED = EpiKind<EPI>::fused;
-    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][LONG_CHUNK + 8];                               // (value, x): the full chain
-    __shared__ double2 s_m[FUSED ? ITS_BLOCK / ITS_WAVE : 1][FUSED ? LONG_CHUNK + 8 : 1];        // the same with excluded entries as (0, 0)
+    __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][LONG_CHUNK + LONG_PAD];                        // (value, x): the full chain
+    __shared__ double2 s_m[FUSED ? ITS_BLOCK / ITS_WAVE : 1][FUSED ? LONG_CHUNK + LONG_PAD : 1]; // the same with excluded entries as (0, 0)
     __shared__ double s_red[4];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int64_t wstride = (int64_t)gridDim.x * (ITS_BLOCK / ITS_WAVE);
@@ -397,6 +409,27 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
 #define LONG_RD(S, N, qv) _Pragma("unroll") for (int u = 0; u < (N); ++u) S[u] = strip[(qv) + u];
 #define LONG_FMA(S, N, cnt) _Pragma("unroll") for (int u = 0; u < (N); ++u) if (u < (cnt)) acc1 = fma(S[u].x, S[u].y, acc1);
                 int q = 0;
+#if ITS_LONG_PIPE
+                if (ne >= 2 * LONG_PIPE_W) {
+                    // two register sets, each reloaded in place right after its multiply-adds: the reads of one batch are in
+                    // flight during the other's chain (the last reload may run past the row's end, inside the strip's pad)
+                    double2 pa[LONG_PIPE_W], pb[LONG_PIPE_W];
+                    LONG_RD(pa, LONG_PIPE_W, 0)
+                    // (the empty asm ties the order down: without it the scheduler hoists the reload above the chain that
+                    // still reads the set, and pays with 32 register copies per trip, or moves a chain above the reads meant to run beside it)
+                    for (; q + 2 * LONG_PIPE_W <= ne; q += 2 * LONG_PIPE_W) {
+                        LONG_RD(pb, LONG_PIPE_W, q + LONG_PIPE_W)
+                        asm volatile("" : "+v"(acc1) :: "memory");
+                        LONG_FMA(pa, LONG_PIPE_W, LONG_PIPE_W)
+                        asm volatile("" : "+v"(acc1) :: "memory");
+                        LONG_RD(pa, LONG_PIPE_W, q + 2 * LONG_PIPE_W)
+                        asm volatile("" : "+v"(acc1) :: "memory");
+                        LONG_FMA(pb, LONG_PIPE_W, LONG_PIPE_W)
+                        asm volatile("" : "+v"(acc1) :: "memory");
+                    }
+                    if (q + LONG_PIPE_W <= ne) { LONG_FMA(pa, LONG_PIPE_W, LONG_PIPE_W) q += LONG_PIPE_W; }
+                }
+#endif
                 for (; q + LONG_WALK <= ne; q += LONG_WALK) {
                     double2 pw[LONG_WALK];
                     LONG_RD(pw, LONG_WALK, q)
@@ -404,7 +437,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
                 }
                 for (; q < ne; q += 8) {
                     double2 p8[8];
-                    LONG_RD(p8, 8, q)                  // (the strip is 8 entries longer than a chunk)
+                    LONG_RD(p8, 8, q)                  // (the strip is longer than a chunk)
                     LONG_FMA(p8, 8, ne - q)
                 }
 #undef LONG_RD
