@@ -335,6 +335,15 @@ constexpr int LONG_WALK = ITS_LONG_WALK;            // entries per batch of the 
 #ifndef ITS_LONG_PIPE
 #define ITS_LONG_PIPE 1
 #endif
+#ifndef ITS_LONG_LANEWALK
+#define ITS_LONG_LANEWALK 16                        // entries per lane of the register walk (0: every epilogue walks out of LDS)
+#endif
+#ifndef ITS_LONG_LANEWALK_MIN
+#define ITS_LONG_LANEWALK_MIN 2048
+#endif
+constexpr int LW_MIN_LEN = ITS_LONG_LANEWALK_MIN;   // rows at least this long take the register walk: its loads are one lane, one
+                                                    // cache line, and a short row leaves most lanes of its 1024-entry chunk idle
+                                                    // (all rows on it: SpMV of the 10 M-row matrix 0.944 -> 0.990 ms)
 #ifndef ITS_LONG_PIPE_W
 #define ITS_LONG_PIPE_W 12
 #endif
@@ -368,9 +377,66 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
     // four SIMDs of a CU, so the longest rows each get a SIMD of their own to start with and share it only with rows a
     // thousand ranks further down (dealt the other way — wave 0 of every workgroup takes the top ranks — the longest walks
     // all land on SIMD 0 of their CUs and time-slice each other: 275 us instead of the walk of one 8192-entry row)
+#if ITS_LONG_LANEWALK
+    // Epilogues that leave no entry out: the chain walks through the LANES' OWN REGISTERS.  A wave gets one LDS read through
+    // every 12 cycles whatever its width (tools/ldsrate.hip), so a chain fed from LDS cannot go below 5 ns per entry; here
+    // lane j holds LW_M CONSECUTIVE entries of the chunk, every lane runs the LW_M multiply-adds on its own entries from
+    // the running sum, and the sum of lane j — the one lane whose input was the true sum — is handed to all lanes for step
+    // j + 1 (two v_readlane): LW_M dependent multiply-adds and one hand-over per step, no LDS.  Same entries, same order,
+    // same operation per entry: the same bits.  Entries past the row's end are staged as (0, 0): fma(0, 0, s) = s.
+    if constexpr (!COLS && !FUSED) {
+        constexpr int LW_M = ITS_LONG_LANEWALK, LW_CH = LW_M * ITS_WAVE;
+        for (int64_t k = (int64_t)blockIdx.x * (ITS_BLOCK / ITS_WAVE) + w; k < n_long; k += wstride) {
+            const int row = rows[k];
+            const int rj0 = rp[row], rj1 = rp[row + 1];
+            if (rj1 - rj0 < LW_MIN_LEN) continue;        // (the loop below takes it)
+            int cn[LW_M]; double vn[LW_M], v1[LW_M], x1[LW_M], vv[LW_M], xg[LW_M];
+#define LW_LOAD_CV(c0v)                                                                   \
+            _Pragma("unroll") for (int u = 0; u < LW_M; ++u) {                            \
+                const int e_ = (c0v) + l * LW_M + u;                                      \
+                cn[u] = e_ < rj1 ? col[e_] : 0;                                           \
+                vn[u] = e_ < rj1 ? val[e_] : 0.0;                                         \
+            }
+#define LW_GATHER(c0v)                                                                    \
+            _Pragma("unroll") for (int u = 0; u < LW_M; ++u) {                            \
+                const int e_ = (c0v) + l * LW_M + u;                                      \
+                v1[u] = vn[u]; x1[u] = e_ < rj1 ? a.x[cn[u]] : 0.0;                       \
+            }
+            LW_LOAD_CV(rj0)
+            LW_GATHER(rj0)
+            LW_LOAD_CV(rj0 + LW_CH)
+            double acc = 0.0;                            // the running sum: the same value in every lane
+            for (int c0 = rj0; c0 < rj1; c0 += LW_CH) {
+#pragma unroll
+                for (int u = 0; u < LW_M; ++u) { vv[u] = v1[u]; xg[u] = x1[u]; }
+                LW_GATHER(c0 + LW_CH)
+                LW_LOAD_CV(c0 + 2 * LW_CH)
+                const int nsteps = (min(LW_CH, rj1 - c0) + LW_M - 1) / LW_M;
+                for (int j = 0; j < nsteps; ++j) {
+                    double s_ = acc;
+#pragma unroll
+                    for (int u = 0; u < LW_M; ++u) s_ = fma(vv[u], xg[u], s_);
+                    acc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s_), j),
+                                           __builtin_amdgcn_readlane(__double2loint(s_), j));
+                }
+            }
+#undef LW_LOAD_CV
+#undef LW_GATHER
+            if (l == 0) {
+                double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+                epi_operands<EPI, DOT>(a, row, e0, e1, e2);
+                const double outv = row_finish<EPI, DOT>(acc, 0.0, 0.0, e0, e1, e2, lane_sum, lane_max);
+                if (a.y) a.y[row] = outv;
+            }
+        }
+    }
+#endif
     for (int64_t k = (int64_t)blockIdx.x * (ITS_BLOCK / ITS_WAVE) + w; k < n_long; k += wstride) {
         const int row = rows[k];
         const int rj0 = rp[row], rj1 = rp[row + 1];
+#if ITS_LONG_LANEWALK
+        if (!COLS && !FUSED && rj1 - rj0 >= LW_MIN_LEN) continue;      // (walked above)
+#endif
         double acc1 = 0.0;                               // this lane's chain (lane 0: the epilogue's own, lane 1: the full one of the fused forms)
         double dg_l = 0.0; int dg_at = -1;               // Jacobi forms: the diagonal entry this lane staged last, and where
         int cn[LONG_LPL], cc[LONG_LPL]; double vn[LONG_LPL], vv[LONG_LPL], xg[LONG_LPL];

@@ -40,6 +40,8 @@ def test_spmv_generated(gpu_handle, name):
     (70000, 6, 5, ((69999, 300),)),
     # either side of SPMV_SOLO_LEN (256) and of the row block's capacity (1536), neighbours, first and last row
     (5000, 10, 4, ((0, 257), (1, 256), (2, 1000), (3, 1536), (4, 1537), (2500, 600), (2501, 700), (4999, 258))),
+    # rows at / around the register walk's threshold (2048) and its 1024-entry chunks
+    (4100, 8, 0, ((7, 2048), (8, 2049), (9, 3072), (10, 4095), (11, 2047), (12, 3073), (4099, 4096))),
 ])
 def test_spmv_ragged(gpu_handle, n, max_len, empty_every, long_rows):
     rp, col, val = random_crs(n, max_len, seed=n, empty_every=empty_every, long_rows=long_rows)
