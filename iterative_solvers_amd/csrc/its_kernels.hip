@@ -1566,6 +1566,7 @@ void launch_gmres_update_x(double *x, const double *x0, const double *V, int64_t
 // the row length; the level's long rows run side by side.
 constexpr int SWEEP_LPL = 8;                        // entries of a long row per lane per chunk
 constexpr int SWEEP_CHUNK = SWEEP_LPL * ITS_WAVE;   // entries of a long row staged per trip
+constexpr int SWEEP_LW_M = 16, SWEEP_LW_MIN = 2048;  // the register walk of the longest rows: entries per lane, shortest row that takes it
 constexpr int SWEEP_MERGE_ROWS = 1 << 18;           // levels up to this size with both kinds of rows go out as one launch
 
 __device__ __forceinline__ void sweep_short_rows(
@@ -1617,6 +1618,45 @@ __device__ __forceinline__ void sweep_long_rows(
         const int row = rows[k];
         const int rj0 = rp[row], rj1 = rp[row + 1];
         double acc = 0.0;
+        if (rj1 - rj0 >= SWEEP_LW_MIN) {
+            // The longest rows: the chain walks through the lanes' own registers instead of LDS (spmv_long_kernel,
+            // its_panel.hip: lane j holds SWEEP_LW_M consecutive entries, every lane runs its multiply-adds from the running
+            // sum, lane j's result is handed to all lanes for step j + 1).  Same entries, same order, same bits.
+            constexpr int M = SWEEP_LW_M, CH = M * ITS_WAVE;
+            int cn[M]; double vn[M], v1[M], x1[M], vv[M], xg[M];
+#define SWEEP_LW_LOAD(c0v)                                                                \
+            _Pragma("unroll") for (int u = 0; u < M; ++u) {                               \
+                const int e_ = (c0v) + l * M + u;                                         \
+                cn[u] = e_ < rj1 ? col[e_] : 0;                                           \
+                vn[u] = e_ < rj1 ? val[e_] : 0.0;                                         \
+            }
+#define SWEEP_LW_GATHER(c0v)                                                              \
+            _Pragma("unroll") for (int u = 0; u < M; ++u) {                               \
+                const int e_ = (c0v) + l * M + u;                                         \
+                v1[u] = vn[u]; x1[u] = e_ < rj1 ? x[cn[u]] : 0.0;                         \
+            }
+            SWEEP_LW_LOAD(rj0)
+            SWEEP_LW_GATHER(rj0)
+            SWEEP_LW_LOAD(rj0 + CH)
+            for (int c0 = rj0; c0 < rj1; c0 += CH) {
+#pragma unroll
+                for (int u = 0; u < M; ++u) { vv[u] = v1[u]; xg[u] = x1[u]; }
+                SWEEP_LW_GATHER(c0 + CH)
+                SWEEP_LW_LOAD(c0 + 2 * CH)
+                const int nsteps = (min(CH, rj1 - c0) + M - 1) / M;
+                for (int j = 0; j < nsteps; ++j) {
+                    double s_ = acc;
+#pragma unroll
+                    for (int u = 0; u < M; ++u) s_ = fma(vv[u], xg[u], s_);
+                    acc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s_), j),
+                                           __builtin_amdgcn_readlane(__double2loint(s_), j));
+                }
+            }
+#undef SWEEP_LW_LOAD
+#undef SWEEP_LW_GATHER
+            if (l == 0) x[row] = (rhs[row] - acc) / D[row];
+            continue;
+        }
         int cn[SWEEP_LPL];                    // columns of the chunk after next
         double vn[SWEEP_LPL];                 // its values
         double vv[SWEEP_LPL], xg[SWEEP_LPL];  // (val, x[col]) of the next chunk
