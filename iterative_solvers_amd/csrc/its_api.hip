@@ -524,6 +524,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->mgs_inject_fail = value;
         return ITS_OK;
     }
+    if (!strcmp(name, "gmres_persist_inject_kind")) {       // 1: workgroup 0 never publishes; 2: a follower gives up at the last step
+        if (value < 1 || value > 2) FAIL(h, ITS_EINVAL, "gmres_persist_inject_kind: 1 or 2");
+        h->mgs_inject_kind = value;
+        return ITS_OK;
+    }
     if (!strcmp(name, "gmres_persist_min_n")) {
         if (value < 1) FAIL(h, ITS_EINVAL, "gmres_persist_min_n >= 1");
         if (h->setup_done && h->solver == ITS_GMRES) FAIL(h, ITS_ESTATE, "set gmres_persist_min_n before its_solver_setup");
@@ -1223,18 +1228,20 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     const bool use_copy = readback_mode() == 2 && h->mgs_grid <= 0;
     const bool hcol_pinned = !use_copy;
     double *hcol_out = hcol_pinned ? h->pinned + h->pin_h : h->hcol_dev;
-    // every entry of the column is armed, not only the last one: the entries come from k + 2 different kernels, and that
-    // the host sees their writes in launch order is an assumption about the path from the XCDs to host memory.  (One
-    // its_solve -gm run printed a history that a stale entry of the previous column would explain; never reproduced
-    // — DESIGN.md §4 — but the assumption is not needed.)
-    static const bool arm_last_only = getenv("ITS_GMRES_ARM_LAST_ONLY") != nullptr;     // the old protocol, for A/B runs of tools/repeat_cli.sh
-    if (hcol_pinned) for (int i = arm_last_only ? k + 1 : 0; i <= k + 1; ++i) arm_pinned_word(hcol_out + i);
+    // Every entry of the column is armed and waited for, not only the last one.  The entries come from k + 2 different
+    // kernels, and the host does NOT see their writes to pinned memory in launch order: one its_solve -gm run on lap3d_16
+    // printed 2.38e-6 for the reference's 1.75e-6 at trip 36, and tools/gmres_stale_entry_probe.py reproduces exactly that
+    // number on the CPU by giving entry k - 1 of column k (written by the third-last kernel of the trip) the value the
+    // slot held in column k - 1 — no other single substitution does (profiles/r03_gmres_stale_probe.txt).
+    // Stores of different kernels to host memory are posted writes that may pass each other on the way; an arrival word
+    // per entry needs no ordering at all.
+    if (hcol_pinned) for (int i = 0; i <= k + 1; ++i) arm_pinned_word(hcol_out + i);
     // the whole sweep as one persistent launch with w in registers (its_mgs.hip) when the set-up found it applicable;
     // w in memory is not modified by it, so a launch that gave up (grid not co-resident) is repeated by the per-step kernels
     bool persist = h->mgs_grid > 0 && hcol_pinned;
     if (persist) {
         HIPCHK(h, launch_mgs_persist(w, h->V, (int64_t)ld, k + 1, h->V + (size_t)(k + 1) * ld, hcol_out, h->mgs_slots, h->mgs_parity++, m, h->mgs_grid, n, h->stream,
-                                     h->mgs_inject_fail > 0 ? h->mgs_inject_fail-- : 0));
+                                     h->mgs_inject_fail > 0 ? (h->mgs_inject_fail--, h->mgs_inject_kind) : 0));
         if ((rc = wait_pinned_word(h, hcol_out + (k + 1)))) return rc;
         if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + (k + 1)) == kPendingWord) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1286,6 +1293,14 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
         for (int i = 0; i <= k; ++i)                                       // (arrived long ago in all but the rare case)
             if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + i) == kPendingWord && (rc = wait_pinned_word(h, hcol_out + i))) return rc;
         std::atomic_thread_fence(std::memory_order_acquire);
+        // wait_pinned_word ends in a stream synchronize when a word does not arrive: an entry that is still armed after
+        // that was never written — an error of this library, reported instead of entering H as a NaN
+        for (int i = 0; i <= k + 1; ++i)
+            if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + i) == kPendingWord) {
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + i) == kPendingWord)
+                    FAIL(h, ITS_ESTATE, "GMRES: an entry of the Hessenberg column was never written to the read-back buffer");
+            }
         for (int i = 0; i <= k + 1; ++i) hc[i] = hcol_out[i];
     } else {
         HIPCHK(h, hipMemcpyAsync(h->pinned + h->pin_copy, h->hcol_dev, (size_t)(k + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -55,6 +55,7 @@ struct its_handle {
     int gmres_persist = 1, gmres_persist_min_n = 1;
     unsigned long long *mgs_slots = nullptr;
     int mgs_grid = 0, mgs_fallbacks = 0, mgs_parity = 0;
+    int mgs_inject_kind = 1;              // option "gmres_persist_inject_kind": who gives up (its_mgs.hip)
     int mgs_inject_fail = 0;              // option "gmres_persist_inject_fail" (tests): launches that give up on purpose
     double *pcg_w = nullptr, *pcg_s = nullptr, *pcg_z = nullptr;     // pipelined CG: w = A r, s = A p, z = A s
     double *pcg_pair[2] = {nullptr, nullptr};                        // (r,r) and (w,r) partials, double-buffered by trip parity

@@ -21,6 +21,13 @@
 // own OpenMP reductions do from run to run.
 // Every wait is bounded by wall-clock time: a grid that is not co-resident (another process on the card) ends, writes
 // nothing but slots, and the caller falls back to the per-step kernels for that trip — w in memory is never modified.
+// How the host learns of it: H[k+1,k] (h_out[nv]) stays armed.  A workgroup that gives up at a step j < nv never
+// publishes its slot of step j + 1, so workgroup 0 gives up there.  At the LAST step there is no next step: a follower
+// that runs out of time there claims its copy of the published sum with a compare-and-swap (sentinel -> MGS_GAVEUP), and
+// workgroup 0 publishes that step with compare-and-swaps too — exactly one of the two wins a word, so either the
+// follower gets the sum after all or workgroup 0 learns that somebody left and does not write h_out[nv] (round 3; before,
+// such a follower returned without its slice of v_{k+1} and the host accepted the trip).  Followers also wait twice as
+// long as workgroup 0, so a sum published within its limit is seen.
 #include "its_kernels.h"
 
 namespace its {
@@ -31,7 +38,8 @@ constexpr int MGS_NWD = 15;                       // data waves per workgroup (+
 constexpr int MGS_NT = MGS_NWD * 64;
 constexpr int MGS_KQ = 8;                         // slots per polling lane: G <= 512
 constexpr int MGS_NB = 16;                        // copies of the published sum (slot layout: MGS_NB x bst words, then G per step)
-constexpr long long MGS_WAIT_TICKS = 2000000;     // 20 ms of the 100 MHz wall clock
+constexpr unsigned long long MGS_GAVEUP = ~0ull - 1;  // left in a published-sum word by a follower that ran out of time at the last step
+constexpr long long MGS_WAIT_TICKS = 2000000;     // 20 ms of the 100 MHz wall clock (workgroup 0; the followers wait twice as long)
 
 __device__ __forceinline__ double mgs_wave_sum(double v)
 {
@@ -42,8 +50,15 @@ __device__ __forceinline__ double mgs_wave_sum(double v)
 __device__ __forceinline__ void mgs_publish(unsigned long long *slot, double v)
 {
     unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-    if (bits == MGS_SENT) bits = MGS_QNAN;        // a NaN with that payload would read as "not there yet"
+    if (bits == MGS_SENT || bits == MGS_GAVEUP) bits = MGS_QNAN;        // a NaN with that payload would read as "not there yet" / "gave up"
     __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the last step's sum: published only into words nobody has given up on; false when a follower was there first
+__device__ __forceinline__ bool mgs_publish_claim(unsigned long long *slot, double v)
+{
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v), expect = MGS_SENT;
+    if (bits == MGS_SENT || bits == MGS_GAVEUP) bits = MGS_QNAN;
+    return __hip_atomic_compare_exchange_strong(slot, &expect, bits, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int EP>
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(MGS_NT + 64) void mgs_persist_kernel(
             }
             double acc = 0.0; bool fail = false;
             const long long t0 = wall_clock64();
-            if (blockIdx.x == 0 && inject_fail) {
+            if (blockIdx.x == 0 && inject_fail == 1) {
                 fail = true;                                     // test hook: workgroup 0 never publishes, the others run into their time limit
             } else if (blockIdx.x == 0) {
                 // all of a lane's slots are asked for at once; only those still pending are asked for again
@@ -128,12 +143,25 @@ __global__ __launch_bounds__(MGS_NT + 64) void mgs_persist_kernel(
 #pragma unroll
                 for (int u = 0; u < MGS_KQ; ++u) if (lane + u * 64 < G && b[u] != MGS_SENT) acc += __longlong_as_double((long long)b[u]);
                 acc = mgs_wave_sum(acc);
-                if (!fail && lane < MGS_NB) mgs_publish(bc + (size_t)lane * bst, acc);
+                if (inject_fail == 2 && j == nv) while (wall_clock64() - t0 < 20000) { }      // test hook: 0.2 ms late, the follower below is first
+                if (!fail && lane < MGS_NB) {
+                    if (j < nv) mgs_publish(bc + (size_t)lane * bst, acc);
+                    else if (!mgs_publish_claim(bc + (size_t)lane * bst, acc)) fail = true;   // a follower has left: no H[k+1,k]
+                }
+                fail = __any(fail);
             } else {
                 unsigned long long b;
-                const unsigned long long *mine = bc + (size_t)(blockIdx.x % MGS_NB) * bst;
-                for (int spins = 0; (b = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == MGS_SENT; ++spins)
-                    if ((spins & 63) == 63 && wall_clock64() - t0 > MGS_WAIT_TICKS) { fail = true; break; }
+                unsigned long long *mine = bc + (size_t)(blockIdx.x % MGS_NB) * bst;
+                bool late = inject_fail == 2 && j == nv && blockIdx.x == 1;                   // test hook: gives up at the last step at once
+                if (!late)
+                    for (int spins = 0; (b = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == MGS_SENT; ++spins)
+                        if ((spins & 63) == 63 && wall_clock64() - t0 > 2 * MGS_WAIT_TICKS) { late = true; break; }
+                if (late && j == nv) {
+                    // the last step has no next one in which workgroup 0 would miss this workgroup: claim the word
+                    b = MGS_SENT;
+                    late = __hip_atomic_compare_exchange_strong(mine, &b, MGS_GAVEUP, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }                                                                             // (lost: b is what was there — the sum, or another's MGS_GAVEUP)
+                fail = late || b == MGS_GAVEUP;
                 acc = __longlong_as_double((long long)b);
             }
             if (lane == 0) { s_h = acc; if (fail) s_fail = 1; }

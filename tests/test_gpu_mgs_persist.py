@@ -72,14 +72,17 @@ def test_persistent_launch_agrees_with_per_step_kernels(gen, restart):
     assert np.max(np.abs(x1 - x0)) <= 1e-11 * np.max(np.abs(x0))
 
 
-@pytest.mark.parametrize("failures", [1, 2])
-def test_launch_that_gives_up_is_repeated_by_the_per_step_kernels(failures):
-    """Workgroup 0 of the first `failures` launches never publishes (test hook), the other workgroups run into their
-    20 ms limit, the launch ends having written nothing that counts and the trip is redone with one launch per basis
-    vector: those trips carry exactly the per-step path's bits; after two such trips the handle stays on that path."""
+@pytest.mark.parametrize("failures,kind", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_launch_that_gives_up_is_repeated_by_the_per_step_kernels(failures, kind):
+    """kind 1: workgroup 0 of the first `failures` launches never publishes (test hook), the other workgroups run into
+    their limit.  kind 2: a FOLLOWER gives up at the last step of the sweep — where no later step exists in
+    which workgroup 0 would miss it — by claiming its copy of the published sum; workgroup 0's publication of that step
+    finds the word taken and leaves H[k+1,k] unwritten.  Either way the launch ends having written nothing that counts
+    and the trip is redone with one launch per basis vector: those trips carry exactly the per-step path's bits; after
+    two such trips the handle stays on that path."""
     rp, col, val = matgen.convdiff3d_27pt(16)
     restart, trips = 8, 12
-    h1, x1, i1 = _solve(rp, col, val, restart, trips, dict(FORCE, gmres_persist_inject_fail=failures))
+    h1, x1, i1 = _solve(rp, col, val, restart, trips, dict(FORCE, gmres_persist_inject_kind=kind, gmres_persist_inject_fail=failures))
     h0, x0, i0 = _solve(rp, col, val, restart, trips, {"gmres_persist": 0})
     hp, xp, ip = _solve(rp, col, val, restart, trips, FORCE)
     assert i1["fallbacks"] == failures and i1["persist_grid"] == (0 if failures >= 2 else ip["persist_grid"])
