@@ -205,13 +205,19 @@ int its_last_region_ms(its_handle *h, float *ms);
 /* average duration (ms) of the SpMV launch INSIDE the last its_iterate_n CG region (HIP event
  * pairs around each of the first 256 launches, on the handle's stream) */
 int its_last_spmv_ms(its_handle *h, float *ms);
-/* which kernel family a whole-matrix exact SpMV (with_dot = 1: the CG form) of this matrix runs on — "spmv_ell_kernel",
+/* which kernel family a whole-matrix exact SpMV (with_dot = 1: the CG form) of this matrix runs on — "spmv_ell_kernel", "spmv_ellw_kernel", "spmv_ellg_kernel",
  * "spmv_stream4_kernel", "spmv_stream2_kernel", "spmv_stream5_kernel", "spmv_irr_kernel" — and the bytes one launch
  * is asked to stream in that kernel's storage form (matrix arrays + x once + y once) */
 int its_spmv_kernel_info(its_handle *h, int which, int with_dot, char *name, int cap, int64_t *streamed_bytes);
 /* plan facts: lanes per row chosen, SELL occupancy (nnz / stored elements), row-block count */
 int its_plan_info(its_handle *h, int which, int format, int *lanes_per_row, double *sell_occupancy,
                   int *n_row_blocks);
+/* sliced-ELL image of an uploaded matrix (what sparse_matrix.hpp:11-64's CRS arrays become for the exact SpMV of short
+ * rows): kind 0 = none, 1 = nibble dictionary indices (rows <= 8 entries, <= 15 distinct col - row), 2 = byte dictionary
+ * indices (rows <= 32, <= 255), 3 = explicit columns as a base per (slice of 128 rows, slot) + 8/16/32-bit deltas (rows
+ * <= 8, any columns); width = slots per row; index_words = 32-bit index words stored; slices_by_delta_width[3] = slices
+ * of kind 3 that use 8- / 16- / 32-bit deltas (zeros otherwise).  Any pointer may be NULL. */
+int its_ell_info(its_handle *h, int which, int *kind, int *width, int64_t *index_words, int *slices_by_delta_width);
 /* after its_solver_setup(ITS_GMRES): workgroups of the persistent Gram-Schmidt launch ("gmres_persist"; 0 = the trips
  * run one launch per basis vector) and how many trips had to be repeated that way because the launch gave up */
 int its_gmres_info(its_handle *h, int *persist_grid, int *fallbacks);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "its_spmv_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, _c_i64_p]),
     "its_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_int_p, _c_dbl_p, _c_int_p]),
     "its_gmres_info": (C.c_int, [C.c_void_p, _c_int_p, _c_int_p]),
+    "its_ell_info": (C.c_int, [C.c_void_p, C.c_int, _c_int_p, _c_int_p, C.POINTER(C.c_int64), _c_int_p]),
     "its_extract_diag": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "its_split_lu": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
     "its_multicolor_order": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _c_int_p]),
@@ -277,6 +278,14 @@ class Handle:
         lpr, occ, nb = C.c_int(), C.c_double(), C.c_int()
         self.check(self.L.its_plan_info(self.h, which, fmt, C.byref(lpr), C.byref(occ), C.byref(nb)), "its_plan_info")
         return {"lanes_per_row": lpr.value, "sell_occupancy": occ.value, "n_row_blocks": nb.value}
+
+    def ell_info(self, which=MAT_A):
+        """sliced-ELL image of the matrix: kind (0 none, 1 nibble dictionary, 2 byte dictionary, 3 explicit columns), slots
+        per row, index words, and for kind 3 the slices that use 8- / 16- / 32-bit column deltas."""
+        k, w, iw = C.c_int(), C.c_int(), C.c_int64()
+        hist = (C.c_int * 3)()
+        self.check(self.L.its_ell_info(self.h, which, C.byref(k), C.byref(w), C.byref(iw), hist), "its_ell_info")
+        return {"kind": k.value, "width": w.value, "index_words": iw.value, "slices_by_delta_width": list(hist)}
 
     def gmres_info(self):
         g, f = C.c_int(), C.c_int()

@@ -47,7 +47,7 @@ static void free_csr(CsrDev &A)
 {
     dfree(A.row_ptr); dfree(A.col); dfree(A.val); dfree(A.blk_desc); dfree(A.blk_desc_big); dfree(A.blk_desc_short); dfree(A.irr_long_rows);
     dfree(A.sell_chunk_ptr); dfree(A.sell_chunk_len); dfree(A.sell_col); dfree(A.sell_perm); dfree(A.sell_val); dfree(A.sell_grp_start); dfree(A.cidx); dfree(A.off_dict); dfree(A.vidx); dfree(A.val_dict);
-    dfree(A.ell_val); dfree(A.ell_idx);
+    dfree(A.ell_val); dfree(A.ell_idx); dfree(A.ellg_desc); dfree(A.ellg_base);
     dfree(A.pan_key); dfree(A.pan_val); dfree(A.pan_desc); dfree(A.pan_tile_ptr); dfree(A.pan_tile_row); dfree(A.pan_long); dfree(A.pan_diag); dfree(A.pan_long_rows);
     dfree(A.mix_rp_d); dfree(A.mix_col_d); dfree(A.mix_val_d); dfree(A.mix_rp_s); dfree(A.mix_col_s); dfree(A.mix_val_s);
     A = CsrDev();
@@ -411,13 +411,27 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     }
     // sliced ELL image for short regular rows (its_ell.hip), built on the device from the arrays just uploaded
     {
-        const bool narrow = A.n_off >= 1 && A.n_off <= ELL_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELL_MAX_W;
-        const bool wide = !narrow && A.n_off >= 1 && A.n_off <= ELLW_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELLW_MAX_W;
-        if ((narrow || wide) && n_rows > 0 && getenv("ITS_NO_ELL") == nullptr) {
+        const bool dict_forms = ell_dict_forms_enabled();
+        const bool narrow = dict_forms && A.n_off >= 1 && A.n_off <= ELL_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELL_MAX_W;
+        const bool wide = dict_forms && !narrow && A.n_off >= 1 && A.n_off <= ELLW_MAX_OFF && A.max_row_len >= 1 && A.max_row_len <= ELLW_MAX_W;
+        // explicit columns (its_ellg.hip): any matrix with rows of <= 8 entries that has no dictionary image
+        const bool generic = !narrow && !wide && A.max_row_len >= 1 && A.max_row_len <= ELL_MAX_W && getenv("ITS_NO_ELLG") == nullptr;
+        if ((narrow || wide || generic) && n_rows > 0 && getenv("ITS_NO_ELL") == nullptr) {
             const int64_t n_blk = ((int64_t)n_rows + ELL_RB - 1) / ELL_RB;
             const int64_t stored = n_blk * ELL_RB * A.max_row_len;
-            if (stored <= nnz + nnz / 4 + 8 * ELL_RB && stored < ((int64_t)1 << 40)) {
-                A.ell_w = A.max_row_len; A.ell_blocks = (int)n_blk; A.ell_kind = narrow ? 1 : 2;
+            if (stored <= nnz + nnz / 4 + 8 * ELL_RB && stored < ((int64_t)1 << 40) && n_blk < (1 << 24)) {
+                A.ell_w = A.max_row_len; A.ell_blocks = (int)n_blk; A.ell_kind = narrow ? 1 : wide ? 2 : 3;
+                if (generic) {
+                    // period of the work map from the most frequent col - row of a sample of rows (its_host.cpp)
+                    int offs[16]; const int n_offs = its_host::frequent_offsets(n_rows, row_ptr, col, offs, 15);
+                    A.ell_pb = ell_choose_period(offs, n_offs);
+                    const size_t slices = (size_t)n_blk * (ELL_RB / ELL_S);
+                    if (dalloc(h, &A.ell_val, (size_t)stored) || dalloc(h, &A.ellg_desc, slices) || dalloc(h, &A.ellg_base, slices * A.ell_w)) return ITS_EHIP;
+                    HIPCHK(h, ellg_build(A, h->stream, &A.ellg_idx_words, A.ellg_hist));
+                    if (getenv("ITS_DEBUG_ELLG"))
+                        fprintf(stderr, "its: explicit-column ELL image: W = %d, %zu slices (8-bit %d, 16-bit %d, 32-bit %d), %.1f index bytes per row, period %d row blocks\n",
+                                A.ell_w, slices, A.ellg_hist[0], A.ellg_hist[1], A.ellg_hist[2], 4.0 * A.ellg_idx_words / std::max(n_rows, 1), A.ell_pb);
+                } else {
                 {
                     std::vector<int> dict(256);
                     HIPCHK(h, hipMemcpy(dict.data(), A.off_dict, 256 * sizeof(int), hipMemcpyDeviceToHost));
@@ -428,6 +442,7 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
                 launch_ell_build(A, h->stream);
                 HIPCHK(h, hipGetLastError());
                 HIPCHK(h, hipStreamSynchronize(h->stream));
+                }
             }
         }
     }
@@ -590,6 +605,18 @@ extern "C" int its_plan_info(its_handle *h, int which, int format, int *lanes_pe
     if (lanes_per_row) *lanes_per_row = A.lanes_per_row;
     if (sell_occ) *sell_occ = A.sell_elems ? (double)A.nnz / (double)A.sell_elems : 0.0;
     if (n_row_blocks) *n_row_blocks = A.n_blocks;
+    return ITS_OK;
+}
+
+extern "C" int its_ell_info(its_handle *h, int which, int *kind, int *width, int64_t *index_words, int *slices_by_delta_width)
+{
+    if (!h || which < 0 || which > 2 || !h->have[which]) return ITS_EINVAL;
+    const CsrDev &A = h->mat[which];
+    if (kind) *kind = A.ell_val ? A.ell_kind : 0;
+    if (width) *width = A.ell_val ? A.ell_w : 0;
+    const int64_t rows_pad = (int64_t)A.ell_blocks * ELL_RB;
+    if (index_words) *index_words = !A.ell_val ? 0 : A.ell_kind == 3 ? A.ellg_idx_words : A.ell_kind == 2 ? rows_pad * ((A.ell_w + 3) / 4) : rows_pad;
+    if (slices_by_delta_width) for (int i = 0; i < 3; ++i) slices_by_delta_width[i] = (A.ell_val && A.ell_kind == 3) ? A.ellg_hist[i] : 0;
     return ITS_OK;
 }
 

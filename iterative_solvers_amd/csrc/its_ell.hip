@@ -356,6 +356,8 @@ static int g_ell_nt = ell_env("ITS_SPMV_ELL_NT", 1);
 static int g_ellw_grid = ell_env("ITS_SPMV_ELLW_GRID", 768);      // 3 workgroups per CU: the byte-index kernel holds 3 waves per SIMD
 static int g_ell_wide = ell_env("ITS_SPMV_ELL_WIDE", 1);      // 0 = rows of 9..32 entries stay on the CRS stream kernels
 static int g_ell_map = ell_env("ITS_SPMV_ELL_MAP", 1);       // 0 = contiguous eighth per XCD even for far-banded matrices
+static int g_ell_dict = ell_env("ITS_SPMV_ELL_DICT", 1);     // 0 = uploads build no dictionary image: eligible rows get the explicit-column one
+int ell_dict_forms_enabled() { return g_ell_dict; }
 
 int ell_tune(const char *name, int value)
 {
@@ -364,6 +366,7 @@ int ell_tune(const char *name, int value)
     if (!strcmp(name, "spmv_ell_nt")) { if (value < 0 || value > 1) return -1; g_ell_nt = value; return 0; }
     if (!strcmp(name, "spmv_ellw_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_ellw_grid = value; return 0; }
     if (!strcmp(name, "spmv_ell_wide")) { if (value < 0 || value > 1) return -1; g_ell_wide = value; return 0; }
+    if (!strcmp(name, "spmv_ell_dict")) { if (value < 0 || value > 1) return -1; g_ell_dict = value; return 0; }
     if (!strcmp(name, "spmv_ell_map")) { if (value < 0 || value > 1) return -1; g_ell_map = value; return 0; }
     return -2;
 }
@@ -374,6 +377,7 @@ bool spmv_ell_eligible(const CsrDev &A, const SpmvArgs &a, int epi)
 {
     if (!g_ell_on || !A.ell_val || epi == EPI_SWEEP || spmv_valdict_selected(A)) return false;
     if (A.ell_kind == 2 && !g_ell_wide) return false;
+    if (A.ell_kind == 3 && a.y2) return false;                   // (the first-level store of EPI_GS_FUSED is not in that kernel)
     // two rows per lane move as 16-byte accesses: every per-row vector must be 16-byte aligned (solver vectors are)
     return al16p(a.y) && al16p(a.b) && al16p(a.D) && al16p(a.dotv) && (epi != EPI_JACOBI_SHIPPED || al16p(a.x));
 }
@@ -440,6 +444,7 @@ void launch_spmv_ell(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t
     const int pb = g_ell_map ? A.ell_pb : 0;
     // the result of a CG / Jacobi product is read by the very next kernel: plain store; non-temporal otherwise
     const int nt = g_ell_nt;
+    if (A.ell_kind == 3) { launch_spmv_ellg(A, a, epi, grid, pb, nt, s); return; }
     switch (A.ell_w) {
     case 1: launch_ell_w<1>(A, a, epi, grid, pb, nt, s); break;
     case 2: launch_ell_w<2>(A, a, epi, grid, pb, nt, s); break;

@@ -145,6 +145,33 @@ bool offset_dict(int n_rows, const int *rp, const int *col, unsigned char *cidx,
     return true;
 }
 
+int frequent_offsets(int n_rows, const int *rp, const int *col, int *out, int max_out)
+{
+    if (n_rows < 1 || max_out < 1) return 0;
+    const int samples = std::min(n_rows, 4096);
+    std::vector<int> offs;
+    for (int q = 0; q < samples; ++q) {
+        const int i = (int)((int64_t)q * n_rows / samples);
+        for (int k = rp[i]; k < rp[i + 1]; ++k) offs.push_back(col[k] - i);
+    }
+    if (offs.empty()) return 0;
+    std::sort(offs.begin(), offs.end());
+    std::vector<std::pair<int64_t, int>> freq;                      // (-count, offset): sorts by count descending, then offset
+    for (size_t a = 0; a < offs.size();) {
+        size_t b = a;
+        while (b < offs.size() && offs[b] == offs[a]) ++b;
+        freq.emplace_back(-(int64_t)(b - a), offs[a]);
+        a = b;
+    }
+    std::sort(freq.begin(), freq.end());
+    int n = 0;
+    for (auto &f : freq) {
+        if (n >= std::min(max_out, 16) || -f.first * 50 < (int64_t)offs.size()) break;
+        out[n++] = f.second;
+    }
+    return n;
+}
+
 bool value_dict(int64_t nnz, const double *val, unsigned char *vidx, double *dict256, int *n_vals)
 {
     *n_vals = 0;

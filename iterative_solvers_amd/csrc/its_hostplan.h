@@ -11,6 +11,9 @@ int validate_crs(int n_rows, int n_cols, int64_t nnz, const int *rp, const int *
 // column-offset dictionary: cidx[k] = index of col[k] - row(k) in dict (first-occurrence order), n_off = entries used;
 // returns false (n_off = 0) when there are more than 256 distinct offsets
 bool offset_dict(int n_rows, const int *rp, const int *col, unsigned char *cidx, int *dict256, int *n_off);
+// the (at most max_out <= 16) most frequent values of col - row among the entries of <= 4096 evenly spaced sample rows,
+// each carried by at least 2 % of the sampled entries; returns how many (0: no offset stands out).  Deterministic.
+int frequent_offsets(int n_rows, const int *rp, const int *col, int *out, int max_out);
 // value dictionary over the fp64 bit patterns, same rules
 bool value_dict(int64_t nnz, const double *val, unsigned char *vidx, double *dict256, int *n_vals);
 // longest row of every block of a stream plan (blk[nb + 1] row cuts)

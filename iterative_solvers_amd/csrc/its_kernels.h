@@ -77,7 +77,13 @@ struct CsrDev {
     uint32_t *ell_idx = nullptr;
     int ell_w = 0, ell_blocks = 0, ell_pb = 0;
     int ell_kind = 0;                         // 1: nibble index word per row (rows <= 8, <= 15 offsets); 2: byte indices, four to a
-                                              // word, slot-major like the values (rows <= 32, <= 255 offsets)
+                                              // word, slot-major like the values (rows <= 32, <= 255 offsets);
+                                              // 3: explicit columns (rows <= 8, any columns; its_ellg.hip): base per (slice, slot)
+                                              // + 8/16/32-bit deltas, width per slice
+    uint32_t *ellg_desc = nullptr;            // [slices] first index word of the slice / 128 << 2 | width code (0: 8, 1: 16, 2: 32 bits)
+    int *ellg_base = nullptr;                 // [slices * ell_w] smallest column of the slot in the slice
+    int64_t ellg_idx_words = 0;               // index words of the image
+    int ellg_hist[3] = {0, 0, 0};             // slices per width code
     // mixed-precision image (ITS_FMT_MIXED): the entries at or above the threshold as an fp64 CRS, the rest as an
     // fp32 CRS, both in the row order of the original
     int *mix_rp_d = nullptr, *mix_col_d = nullptr, *mix_rp_s = nullptr, *mix_col_s = nullptr;
@@ -161,6 +167,10 @@ bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);     
 void launch_spmv_panel(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 int panel_tune(const char *name, int value);             // "spmv_panel", "spmv_panel_min_cols", "spmv_panel_log2pw", "spmv_panel_grid"
 void launch_spmv_ell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
+// explicit-column form (its_ellg.hip): builder (allocates A.ell_idx; ell_val, ellg_desc, ellg_base are the caller's) and launch
+hipError_t ellg_build(CsrDev &A, hipStream_t s, int64_t *idx_words_out, int *hist);
+void launch_spmv_ellg(const CsrDev &A, const SpmvArgs &a, int epilogue, int grid, int pb, int nt, hipStream_t s);
+int ell_dict_forms_enabled();                            // option "spmv_ell_dict" (its_ell.hip): 0 = uploads build the explicit-column image instead
 void launch_ell_build(const CsrDev &A, hipStream_t s, int row_base = 0);   // fills ell_val / ell_idx from the device CRS arrays
 int ell_tune(const char *name, int value);               // "spmv_ell", "spmv_ell_grid", "spmv_ell_nt", "spmv_ell_map"
 void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);

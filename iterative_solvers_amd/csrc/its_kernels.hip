@@ -921,6 +921,11 @@ const char *spmv_exact_kernel_name(const CsrDev &A, const SpmvArgs &a, int epi, 
     const int64_t csr = (cmp == 2 ? 2 : cmp == 1 ? 9 : 12) * nnz + 4 * (n + 1) + 16 * n;
     if (streamed) *streamed = csr;
     if (spmv_ell_eligible(A, a, epi)) {
+        if (A.ell_kind == 3) {
+            const int64_t slices = (int64_t)A.ell_blocks * (ELL_RB / ELL_S);
+            if (streamed) *streamed = (int64_t)A.ell_blocks * ELL_RB * 8 * A.ell_w + 4 * A.ellg_idx_words + slices * (4 + 4 * A.ell_w) + 16 * n;
+            return "spmv_ellg_kernel";
+        }
         if (A.ell_kind == 2) {
             if (streamed) *streamed = (int64_t)A.ell_blocks * ELL_RB * (8 * A.ell_w + 4 * ((A.ell_w + 3) / 4)) + 16 * n;
             return "spmv_ellw_kernel";
