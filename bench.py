@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the solver hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 256] [--format exact|vector|sell]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 256] [--global-grid G] [--format exact|vector|sell]
 
 Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): conjugate gradient, fp64, 3-D 7-point
-Laplacian, 256^3 rows PER GPU (N GPUs: z-slabs of one 256 x 256 x 256N grid — configs[4] at
-N = 8), b = 1, x0 = 1, no scaling.  One "step" = one CG iteration through the reference's loop
+Laplacian, 16.8 M rows PER GPU, b = 1, x0 = 1, no scaling.  Two named grids:
+  * weak series (default at N = 1, 2, 4): every rank owns a 256^3 slab of one 256 x 256 x 256N grid;
+  * configs[4] (default at N = 8; `--global-grid 512` at any N that divides 512): the ranks share ONE 512^3 grid
+    (134 M rows), rank r owns planes [512 r / N, 512 (r + 1) / N) — at N = 8 that is 64 planes of 512^2 per GPU, the
+    same 16.8 M rows as a 256^3 slab, but halo planes of 2 MiB and a far band 262 144 rows away.
+    `--global-grid 0` forces the weak series.
+One "step" = one CG iteration through the reference's loop
 body (Solver::iterate + record_residual_norm + exchange_arrays, solver_harness.hpp:40-116),
 INCLUDING the per-trip 8-byte residual read-back the harness needs for its stopping test.
 The matrix and all vectors are resident in HBM before the timed region starts.
+Timing: W warm-up trips, then REGIONS (5) regions of exactly K trips, each bracketed by a barrier and a device
+synchronize on both sides, each taken as the MAX over ranks; `value` / `ms_per_step` are the MEDIAN region,
+`ms_per_step_min` / `_max` the fastest and slowest.
 
-Prints ONE JSON line (rank 0): value = CG iterations/s x (number of 256^3 slabs) — whole-job
+Prints ONE JSON line (rank 0): value = CG iterations/s x (number of slabs) — whole-job
 throughput in slab-iterations per second, so weak scaling is value(N) / (N value(1)).
 `roofline` prices the dominant kernel (the CSR SpMV fused with the p.Ap partial sums) against
 the ~8 TB/s HBM peak; `cpu_baseline` times the oracle (CPU restatement of the reference loop,
@@ -50,7 +58,7 @@ def kernel_sources_hash():
     import hashlib
     hsh = hashlib.sha256()
     # the files that hold device code (host-side API changes do not invalidate a counter profile)
-    names = ("its_kernels.hip", "its_ell.hip", "its_panel.hip", "its_mgs.hip", "its_epilogue.h", "its_device.h", "its_kernels.h")
+    names = ("its_kernels.hip", "its_ell.hip", "its_ellg.hip", "its_panel.hip", "its_mgs.hip", "its_epilogue.h", "its_device.h", "its_kernels.h")
     for f in sorted(os.path.join(ROOT, "iterative_solvers_amd", "csrc", nm) for nm in names):
         hsh.update(os.path.basename(f).encode()); hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]
@@ -91,7 +99,7 @@ def pmc_traffic(kernel_substr):
     return 2.0 * fetch * 1024 + write * 1024, f"{name} (kernel sources {stamp}; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
 
 
-def cpu_baseline(rp, col, val, n, budget_s=15.0):
+def cpu_baseline(rp, col, val, n, budget_s=10.0):
     """Oracle CG on the host cores, bounded sample (kind 'port': our restatement of the loop)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py as orc
@@ -102,9 +110,56 @@ def cpu_baseline(rp, col, val, n, budget_s=15.0):
     per_it = max(probe["seconds"] / 2, 1e-6)
     iters = int(max(3, min(200, budget_s / per_it)))
     res = orc.solve(rp, col, val, b, x0, orc.CG, fixed_iters=iters, max_iters=iters)
-    return {"value": iters / res["seconds"], "unit": "it/s", "cores": threads, "kind": "port",
-            "sample": f"{iters} CG iterations (reference loop as written: 1 SpMV + 15 vector passes) "
-                      f"on the same {n}-row system, oracle/libits_oracle.so with {threads} OpenMP threads"}
+    out = {"value": iters / res["seconds"], "unit": "it/s", "cores": threads, "kind": "port",
+           "sample": f"{iters} CG iterations (reference loop as written: 1 SpMV + 15 vector passes) "
+                     f"on the same {n}-row system, oracle/libits_oracle.so with {threads} OpenMP threads"}
+    try:
+        out["calibration"] = cpu_calibration(orc, threads)
+    except Exception as e:                                   # the calibration is an extra: never fails the bench line
+        out["calibration"] = {"error": repr(e)[:200]}
+    return out
+
+
+def cpu_calibration(orc, threads, grid=128):
+    """`kind` is "port": what is timed above is the oracle's restatement of the loop, not the reference binary.  This leg
+    shows that the port runs at the reference's speed: the COMPILED REFERENCE (oracle/_ref/iterative_solvers_cpu_m100, built
+    from /root/reference by oracle/Makefile with plain g++, unmodified) and the port solve the same generated 7-pt
+    Laplacian `grid`^3 .mtx with `-cg -scale none` to the reference's compiled-in TOL = 1e-14, same thread count; the
+    reference's own timers (solver_harness.hpp:41,52 -> "CG Solver time", "Solver Harness time") are parsed."""
+    import re
+    import subprocess
+    import tempfile
+    from iterative_solvers_amd import matgen
+    exe = os.path.join(ROOT, "oracle", "_ref", "iterative_solvers_cpu_m100")
+    if not os.path.exists(exe):
+        return {"error": "oracle/_ref/iterative_solvers_cpu_m100 not built (make -C oracle ref, needs /root/reference)"}
+    rp, col, val = matgen.laplace3d_7pt(grid)
+    n = len(rp) - 1
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, f"lap{grid}.mtx")
+        t0 = time.time()
+        orc.write_mtx(path, rp, col, val)
+        t_write = time.time() - t0
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PLACES="cores", OMP_PROC_BIND="close")
+        t0 = time.time()
+        r = subprocess.run([exe, path, "-cg", "-scale", "none"], env=env, capture_output=True, text=True, timeout=600, cwd=td)
+        t_ref = time.time() - t0
+    if r.returncode != 0:
+        return {"error": f"reference exited with {r.returncode}: {r.stderr[-200:]}"}
+    m = re.search(r"solver converged in: (\d+) iterations", r.stdout)
+    its_ref = int(m.group(1)) if m else 5000                 # MAX_ITERS the reference was compiled with
+    t_cg = float(re.search(r"CG Solver time:\s+(\S+)\[s\]", r.stdout).group(1))
+    t_har = float(re.search(r"Solver Harness time:\s+(\S+)\[s\]", r.stdout).group(1))
+    b = np.ones(n)
+    port = orc.solve(rp, col, val, b, b.copy(), orc.CG, max_iters=5000, tol=1e-14)
+    ref_its, port_its = its_ref / t_har, port["iters"] / port["seconds"]
+    return {"system": f"7-pt Laplacian {grid}^3 ({n} rows, {len(col)} entries) as a generated .mtx, -cg -scale none, TOL 1e-14, {threads} threads",
+            "reference_iterations": its_ref, "reference_harness_seconds": t_har, "reference_cg_solver_seconds": t_cg,
+            "reference_it_per_s": ref_its, "reference_it_per_s_iterate_only": its_ref / t_cg,
+            "port_iterations": port["iters"], "port_seconds": port["seconds"], "port_it_per_s": port_its,
+            "port_over_reference": port_its / ref_its,
+            "note": "reference_it_per_s = iterations / 'Solver Harness time' (iterate + record_residual_norm + exchange_arrays, what the "
+                    "port's clock covers); the reference binary's wall time here was %.1f s (%.1f s writing the .mtx apart), most of it fscanf" % (t_ref, t_write)}
 
 
 GATHER_PEAK = 56.5e9      # random 8-byte gathers/s from an 80 MB table (Infinity Cache resident, not L2): measured ceiling
@@ -154,15 +209,16 @@ def other_configs(capi, matgen, S):
     moved = streamed + float(np.mean([((k + 1) + 2) * 8 * n if persist else (4 * (k + 2) + 2) * 8 * n for k in range(50)]))
     res["c3_gmres50_convdiff27_128"] = {
         "workload": "restarted GMRES(50), 27-pt convection-diffusion 128^3, MGS Arnoldi on device, Givens on host",
-        "rows": n, "nnz": nnz, "ms_per_trip": dt * 1e3, "trips_per_s": 1 / dt, "algorithmic_bytes_per_trip": by,
-        "GBps_algorithmic": by / dt / 1e9, "frac_hbm_peak": by / dt / 1e9 / HBM_PEAK_GBS,
-        "note": "SURVEY 8d prices a Gram-Schmidt step at 5 vector passes; the persistent launch reads each basis vector "
-                "once with w in registers, so the algorithmic figure can exceed what is moved (and 1.0 of peak): "
-                "frac_hbm_peak_moved prices the bytes the kernels are asked for" if persist else "",
+        "rows": n, "nnz": nnz, "ms_per_trip": dt * 1e3, "trips_per_s": 1 / dt,
+        # the config's roofline fraction prices the bytes the kernels are ASKED FOR: SURVEY 8d prices a
+        # Gram-Schmidt step at 5 vector passes, the persistent launch reads each basis vector once with w in registers
+        "frac": moved / dt / 1e9 / HBM_PEAK_GBS, "moved_bytes_per_trip": moved, "GBps_moved": moved / dt / 1e9,
+        "bound": "latency of the k + 2 grid-wide sums of a trip (3.3 us each), not bandwidth" if persist else "hbm",
+        "survey_8d_accounting": {"algorithmic_bytes_per_trip": by, "GBps_algorithmic": by / dt / 1e9, "frac_hbm_peak": by / dt / 1e9 / HBM_PEAK_GBS,
+                                 "note": "5 vector passes per Gram-Schmidt step that the persistent launch no longer makes: can exceed 1.0"},
         "gram_schmidt": f"one persistent launch per trip, {info['persist_grid']} workgroups (fallbacks: {info['fallbacks']})" if persist
                         else "one launch per basis vector",
-        "spmv_kernel": kname, "moved_bytes_per_trip": moved, "GBps_moved": moved / dt / 1e9,
-        "frac_hbm_peak_moved": moved / dt / 1e9 / HBM_PEAK_GBS, "setup_seconds": setup, "generate_seconds": gen3}
+        "spmv_kernel": kname, "setup_seconds": setup, "generate_seconds": gen3}
     h.close()
     del rp, col, val
     # ---- C4
@@ -187,8 +243,10 @@ def other_configs(capi, matgen, S):
             h.iterate(k); k += 1
         h.synchronize()
         dt = (time.perf_counter() - t0) / 30
-        # the reference's trip = sweep + recorded residual (a second product); gathers per trip: one per entry and pass
-        by = 2 * spmv_bytes(n, nnz) + (16 * n if name == "jacobi" else 40 * n)
+        # one Jacobi trip (correct mode, sweep fused with the recorded residual) = one pass over A + b
+        # = 12 nnz + 28 n; a GS trip = b - U x, the sweep over L and the recorded residual: two passes over the entries
+        # (U + L, then A) + the vectors they touch.  Gathers per trip: one per entry and pass.
+        by = (spmv_bytes(n, nnz) + 8 * n) if name == "jacobi" else (2 * spmv_bytes(n, nnz) + 40 * n)
         gathers = nnz if name == "jacobi" else 2 * nnz           # Jacobi: one fused pass over A; GS: U + L, then A
         res["c4_powerlaw_" + name.replace("-", "_")] = {
             "workload": f"{name} on the power-law matrix (10 M rows, {nnz} entries, longest row {int(np.diff(rp).max())})"
@@ -205,7 +263,32 @@ def other_configs(capi, matgen, S):
             res["c4_powerlaw_spmv_exact"] = {"ms": ms, "kernel": h.spmv_kernel_info(capi.MAT_A)[0], "GBps_algorithmic": spmv_bytes(n, nnz) / ms / 1e6,
                                              "frac_hbm_peak": spmv_bytes(n, nnz) / ms / 1e6 / HBM_PEAK_GBS,
                                              "frac_gather_peak": nnz / (ms * 1e-3) / GATHER_PEAK}
+            # configs[3]'s "SELL-C-sigma vs vector-CSR" on the same resident matrix (CUDA_tests/spmv.cpp:264,548-552: GF/s and
+            # the occupancy nnz / stored elements of the SELL image); reordered summation, 1e-12 of the exact result
+            h.spmv_timed(xd, yd, capi.FMT_CSR_VECTOR, reps=3)
+            ms = h.spmv_timed(xd, yd, capi.FMT_CSR_VECTOR, reps=20)
+            res["c4_powerlaw_spmv_vector"] = {"ms": ms, "kernel": "spmv_vector_kernel", "lanes_per_row": h.plan_info(capi.MAT_A)["lanes_per_row"],
+                                              "GBps_algorithmic": spmv_bytes(n, nnz) / ms / 1e6, "GFps": 2.0 * nnz / ms / 1e6,
+                                              "frac_hbm_peak": spmv_bytes(n, nnz) / ms / 1e6 / HBM_PEAK_GBS,
+                                              "frac_gather_peak": nnz / (ms * 1e-3) / GATHER_PEAK}
         h.close()
+    # SELL-64-sigma image of the same matrix (its own upload: the image is built on request)
+    hs = capi.Handle(0)
+    t0 = time.time()
+    hs.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_SELL)
+    setup = time.time() - t0
+    xd = hs.to_dev(np.ones(n)); yd = hs.dev_alloc(8 * n)
+    hs.spmv_timed(xd, yd, capi.FMT_SELL, reps=3)
+    ms = hs.spmv_timed(xd, yd, capi.FMT_SELL, reps=20)
+    occ = hs.plan_info(capi.MAT_A, capi.FMT_SELL)["sell_occupancy"]
+    stored = nnz / occ if occ > 0 else float("nan")
+    sell_bytes = 12 * stored + 8 * (n / 64) + 16 * n              # padding counted as cost
+    res["c4_powerlaw_spmv_sell"] = {"ms": ms, "kernel": "spmv_sell_kernel", "sell_occupancy": occ, "C": 64,
+                                    "GBps_algorithmic": spmv_bytes(n, nnz) / ms / 1e6, "GFps": 2.0 * nnz / ms / 1e6,
+                                    "frac_hbm_peak": spmv_bytes(n, nnz) / ms / 1e6 / HBM_PEAK_GBS, "sell_bytes": sell_bytes,
+                                    "GBps_sell_bytes": sell_bytes / ms / 1e6, "frac_gather_peak": nnz / (ms * 1e-3) / GATHER_PEAK,
+                                    "setup_seconds": setup}
+    hs.close()
     return res
 
 
@@ -257,16 +340,87 @@ def spawn_ranks(n_ranks, argv):
     raise SystemExit(rc)
 
 
+REGIONS = 5                     # timed regions of --steps trips each; `value` is the median region
+
+
+def timed_regions(step, steps, regions, barrier, dist):
+    """`regions` regions of exactly `steps` trips, each bracketed by barrier + device synchronize on both sides and taken
+    as the max over ranks; returns the region times in seconds."""
+    dts = []
+    for _ in range(regions):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dt = dist.allreduce_max(dt)
+        dts.append(dt)
+    return dts
+
+
+def region_stats(dts, steps):
+    ms = sorted(d / steps * 1e3 for d in dts)
+    return {"median": ms[len(ms) // 2], "min": ms[0], "max": ms[-1]}
+
+
+def generic_spmv_entries(h, capi, rp, col, val, n, nnz, xd, yd, reps):
+    """north_star's ">= 80 % of HBM bandwidth" beyond the stencil dictionaries: the exact SpMV of the
+    SAME C2 matrix with every dictionary form switched off — the explicit-column sliced-ELL image any matrix with rows of
+    <= 8 entries gets (csrc/its_ellg.hip) — and of the same matrix with randomly permuted rows (P A: no locality left, 32-bit
+    column deltas, x gathers from all over the vector).  CG form (store + fused p.Ap partial sums), same accounting as
+    `roofline`.  Leaves the handle with the default image of the original matrix."""
+    out = {}
+    h.set_option("spmv_ell_dict", 0)
+    try:
+        # (ITS_BENCH_NO_PERMUTED=1: counter passes, where both matrices would launch the same kernel instantiation)
+        tags = ("exact_generic",) if os.environ.get("ITS_BENCH_NO_PERMUTED", "0") == "1" else ("exact_generic", "exact_generic_rows_permuted")
+        for tag in tags:
+            if tag.endswith("permuted"):
+                perm = np.random.default_rng(7).permutation(n)
+                ln = np.diff(rp)[perm]
+                rq = np.concatenate([[0], np.cumsum(ln)]).astype(np.int32)
+                idx = (np.repeat(rp[:-1][perm].astype(np.int64) - rq[:-1], ln) + np.arange(nnz, dtype=np.int64))
+                t0 = time.time()
+                h.upload_crs(rq, col[idx], val[idx], capi.MAT_A, capi.FMT_CSR_EXACT)
+                del idx, perm
+            else:
+                t0 = time.time()
+                h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+            setup = time.time() - t0
+            kname, streamed = h.spmv_kernel_info(capi.MAT_A, True)
+            info = h.ell_info()
+            h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=3, with_dot=True)
+            ms = h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=reps, with_dot=True)
+            ms_plain = h.spmv_timed(xd, yd, capi.FMT_CSR_EXACT, reps=reps)
+            by = spmv_bytes(n, nnz)
+            traffic, tnote = (pmc_traffic(kname + "<") if tag == "exact_generic" else (None, "not profiled"))
+            out[tag] = {"kernel": "its::" + kname, "ms": ms, "ms_plain_store": ms_plain, "algorithmic_bytes": by, "streamed_bytes": streamed,
+                        "GBps_algorithmic": by / ms / 1e6, "frac": by / ms / 1e6 / HBM_PEAK_GBS, "GBps_streamed": streamed / ms / 1e6,
+                        "traffic": traffic, "traffic_source": tnote, "upload_seconds": setup,
+                        "image": {"slots_per_row": info["width"], "slices_with_8_16_32_bit_deltas": info["slices_by_delta_width"],
+                                  "index_bytes_per_row": 4.0 * info["index_words"] / n}}
+    finally:
+        h.set_option("spmv_ell_dict", 1)
+    h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--grid", type=int, default=256, help="grid edge N: N^3 rows per GPU")
+    ap.add_argument("--grid", type=int, default=256, help="weak series: grid edge N, N^3 rows per GPU")
+    ap.add_argument("--global-grid", type=int, default=None,
+                    help="G > 0: the ranks share ONE G^3 grid, rank r owns planes [G r / N, G (r + 1) / N) (BASELINE configs[4] is "
+                         "G = 512 at N = 8: the default there); 0: the weak series (default at every other N)")
     ap.add_argument("--format", default="exact", choices=["exact", "vector", "sell"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 (GMRES(50) 27-pt 128^3) and C4 (power-law 10 M rows) legs")
+    ap.add_argument("--no-generic", action="store_true", help="skip the spmv.exact_generic entries (the C2 matrix without dictionary forms / with permuted rows)")
     ap.add_argument("--print-source-hash", action="store_true", help="print the kernel-source hash PMC summaries are stamped with")
     a = ap.parse_args()
     if a.print_source_hash:
@@ -295,7 +449,31 @@ def main():
     rdzv = Rendezvous(rank, world)
     dist = rdzv if world > 1 else None
     fmt = {"exact": capi.FMT_CSR_EXACT, "vector": capi.FMT_CSR_VECTOR, "sell": capi.FMT_SELL}[a.format]
-    N = a.grid
+
+    # ---- which grid.  NX = plane edge, PL = planes this rank owns, NZ = planes of the whole grid
+    # ITS_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL communicators, split SpMV, all-reduced
+    # scalars) even at world = 1, to see what that path costs per trip without a second GPU
+    # ITS_BENCH_FORCE_DIST=2: the same, and the rank is its own z-neighbour on both sides (the middle slab of three
+    # with the outer two folded onto it), so the halo planes really travel through pack kernel -> RCCL send/recv ->
+    # boundary SpMV: the whole per-trip cost of the N > 1 path except the xGMI wire (never a reported number).
+    # With --global-grid G the rehearsed slab is one of ITS_BENCH_REHEARSE_RANKS (default 8) slabs of the G^3 grid.
+    force_dist = os.environ.get("ITS_BENCH_FORCE_DIST", "0") in ("1", "2")
+    loopback = os.environ.get("ITS_BENCH_FORCE_DIST", "0") == "2"
+    gg = a.global_grid if a.global_grid is not None else (512 if a.gpus == 8 else 0)
+    if gg > 0:
+        parts = world if world > 1 else (int(os.environ.get("ITS_BENCH_REHEARSE_RANKS", "8")) if force_dist else 1)
+        if gg % parts:
+            raise SystemExit(f"--global-grid {gg} is not divisible into {parts} z-slabs")
+        NX, PL, NZ = gg, gg // parts, gg
+        grid_name = f"{gg}^3 grid shared by {parts} z-slabs of {PL} planes ({NX}x{NX}x{PL} rows per GPU)" if parts > 1 else f"{gg}^3 grid on one GPU"
+        slab_name = f"{NX}x{NX}x{PL}-slab" if parts > 1 else f"{gg}^3"
+        mode = "global-grid"
+    else:
+        NX, PL, NZ = a.grid, a.grid, a.grid * world
+        grid_name = f"{a.grid}^3 rows per GPU (grid {a.grid}x{a.grid}x{a.grid * world})"
+        slab_name = f"{a.grid}^3-slab"
+        mode = "weak-series"
+    P = NX * NX
 
     t_gen = time.time()
     t_matgen = None
@@ -311,15 +489,9 @@ def main():
                          (int(os.environ.get("LOCAL_WORLD_SIZE", world)), n_dev))
     sol = S.Solver("conjugate-gradient", device=0 if host_transport else local_rank % n_dev, spmv_format=fmt)
     h = sol.handle
-    # ITS_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL communicators, split SpMV, all-reduced
-    # scalars) even at world = 1, to see what that path costs per trip without a second GPU
-    # ITS_BENCH_FORCE_DIST=2: the same, and the rank is its own z-neighbour on both sides (the middle slab of three
-    # with the outer two folded onto it), so the halo planes really travel through pack kernel -> RCCL send/recv ->
-    # boundary SpMV: the whole per-trip cost of the N > 1 path except the xGMI wire (never a reported number)
-    force_dist = os.environ.get("ITS_BENCH_FORCE_DIST", "0") in ("1", "2")
-    loopback = os.environ.get("ITS_BENCH_FORCE_DIST", "0") == "2"
+    rp = col = val = None
     if world == 1 and not force_dist:
-        rp, col, val = matgen.laplace3d_7pt(N)
+        rp, col, val = matgen.laplace3d_7pt(NX, PL) if PL != NX else matgen.laplace3d_7pt(NX)
         n = len(rp) - 1
         nnz = len(col)
         t_matgen = time.time() - t_gen
@@ -328,9 +500,11 @@ def main():
     else:
         from iterative_solvers_amd import distributed as D
         if loopback and world == 1:
-            rp, colg, val = matgen.laplace3d_7pt_slab(N, N, 2 * N, 3 * N)
+            rp, colg, val = matgen.laplace3d_7pt_slab(NX, PL, 2 * PL, 3 * PL)
+        elif world == 1:
+            rp, colg, val = matgen.laplace3d_7pt_slab(NX, 0, PL, PL)
         else:
-            rp, colg, val = matgen.laplace3d_7pt_slab(N, rank * N, (rank + 1) * N, world * N)
+            rp, colg, val = matgen.laplace3d_7pt_slab(NX, rank * PL, (rank + 1) * PL, NZ)
         n = len(rp) - 1
         nnz = len(colg)
         if host_transport:
@@ -339,7 +513,6 @@ def main():
             D.init_comm(h, rank, world, rdzv)
         if loopback and world == 1:
             import ctypes as C
-            P = N * N
             colg = np.asarray(colg, dtype=np.int64)
             coll = np.where(colg < n, n + (colg - (n - P)),                    # plane below -> halo [n, n+P)
                             np.where(colg >= 2 * n, n + P + (colg - 2 * n),        # plane above -> halo [n+P, n+2P)
@@ -366,28 +539,27 @@ def main():
         h.synchronize()
 
     it = 0
+
+    def cg_step():
+        nonlocal it
+        h.iterate(it); it += 1
     for _ in range(a.warmup):
-        h.iterate(it); it += 1
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        h.iterate(it); it += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        dt = dist.allreduce_max(dt)
-    ms_per_step = dt / a.steps * 1e3
-    its_per_s = a.steps / dt
+        cg_step()
+    dts = timed_regions(cg_step, a.steps, REGIONS, barrier, dist)
+    st = region_stats(dts, a.steps)
+    ms_per_step = st["median"]
+    its_per_s = 1e3 / ms_per_step
 
     # same loop without the per-trip read-back (one sync at the end) — reported beside `value`
     res = h.iterate_n(it, a.steps); it += a.steps
     async_ms = h.last_region_ms() / a.steps
     inloop_spmv_ms = h.last_spmv_ms()          # HIP event pairs around the SpMV launches of that loop
 
+    c2_single = world == 1 and not force_dist and mode == "weak-series" and a.grid == 256
     out = None
     if rank == 0:
         # dominant kernel: the in-loop SpMV (+ fused p.Ap partials), HIP events on the handle's stream
-        xd = h.to_dev(np.ones(n + 2 * N * N)); yd = h.dev_alloc(8 * n)
+        xd = h.to_dev(np.ones(n + 2 * P)); yd = h.dev_alloc(8 * n)
         roof = None
         spmv_all = {}
         if inloop_spmv_ms > 0:
@@ -396,7 +568,7 @@ def main():
             k_ms = inloop_spmv_ms
             ach = spmv_bytes(n, nnz) / (k_ms * 1e-3) / 1e9
             kname, streamed = h.spmv_kernel_info(capi.MAT_A, True) if fmt == capi.FMT_CSR_EXACT else (a.format, spmv_bytes(n, nnz))
-            traffic, tnote = pmc_traffic(kname + "<") if (fmt == capi.FMT_CSR_EXACT and world == 1 and N == 256) else (None, "not the C2 single-GPU exact run")
+            traffic, tnote = pmc_traffic(kname + "<") if (fmt == capi.FMT_CSR_EXACT and c2_single) else (None, "not the C2 single-GPU exact run")
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": tnote,
                     "kernel": f"its::{kname} (CSR SpMV fused with the p.Ap partial sums)",
@@ -422,10 +594,13 @@ def main():
         if not a.no_cpu and world == 1 and not force_dist:
             cpu = cpu_baseline(rp, col, val, n)
         out = {
-            "metric": "cg_iters_per_sec", "value": its_per_s * world, "unit": f"it/s ({N}^3-slab iterations)",
+            "metric": "cg_iters_per_sec", "value": its_per_s * world, "unit": f"it/s ({slab_name} iterations)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"CG fp64, 3-D 7-pt Laplacian, {N}^3 rows per GPU (grid {N}x{N}x{N * world}), b=1, x0=1, -scale none",
+            "ms_per_step_min": st["min"], "ms_per_step_max": st["max"], "regions": REGIONS,
+            "higher_is_better": True, "scaling": "weak" if (mode == "weak-series" or world == 8) else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"CG fp64, 3-D 7-pt Laplacian, {grid_name}, b=1, x0=1, -scale none",
+                       "grid_mode": mode + (" (BASELINE configs[4])" if (mode == "global-grid" and gg == 512 and world == 8) else ""),
                        "rows_per_gpu": n, "nnz_per_gpu": nnz, "spmv_format": a.format,
                        "parallelism": (f"row-block z-slabs x{world}" + (" (HOST rehearsal transport, one GPU)" if host_transport else " over RCCL")) if world > 1
                                       else ("single GPU, RCCL loopback rehearsal of the N > 1 path" if loopback else "single GPU")},
@@ -447,21 +622,19 @@ def main():
     h.init_residual()
     h.solver_setup(capi.JACOBI, jacobi_mode=capi.JACOBI_REF)
     jt = 0
+
+    def jacobi_step():
+        nonlocal jt
+        h.iterate(jt); jt += 1
     for _ in range(a.warmup):
-        h.iterate(jt); jt += 1
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        h.iterate(jt); jt += 1
-    barrier()
-    jdt = time.perf_counter() - t0
-    if dist is not None:
-        jdt = dist.allreduce_max(jdt)
+        jacobi_step()
+    jst = region_stats(timed_regions(jacobi_step, a.steps, 3, barrier, dist), a.steps)
     if rank == 0:
         # one pass over A per trip (sweep fused with the recorded residual): SpMV bytes + b
         jb = spmv_bytes(n, nnz) + 8 * n
-        out["jacobi"] = {"value": a.steps / jdt * world, "unit": out["unit"], "ms_per_step": jdt / a.steps * 1e3,
-                         "GBps_algorithmic_per_gpu": jb * a.steps / jdt / 1e9}
+        out["jacobi"] = {"value": 1e3 / jst["median"] * world, "unit": out["unit"], "ms_per_step": jst["median"],
+                         "ms_per_step_min": jst["min"], "ms_per_step_max": jst["max"],
+                         "GBps_algorithmic_per_gpu": jb / jst["median"] / 1e6}
     # row-partitioned runs only, opt-in and never `value`: pipelined CG (its_set_option "cg_variant" 1) — one
     # reduction point per trip instead of two — on the same resident system with the same timing protocol, so that the
     # scaling record shows what the second all-reduce of a trip costs on this fabric.  ITS_BENCH_NO_PIPELINED=1 skips it.
@@ -471,25 +644,26 @@ def main():
         h.init_residual()
         h.solver_setup(capi.CG)
         pt = 0
+
+        def pcg_step():
+            nonlocal pt
+            h.iterate(pt); pt += 1
         for _ in range(a.warmup):
-            h.iterate(pt); pt += 1
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            h.iterate(pt); pt += 1
-        barrier()
-        pdt = time.perf_counter() - t0
-        if dist is not None:
-            pdt = dist.allreduce_max(pdt)
+            pcg_step()
+        pst = region_stats(timed_regions(pcg_step, a.steps, 3, barrier, dist), a.steps)
         if rank == 0:
             out["opt_in"] = dict(out.get("opt_in") or {}, pipelined_cg={
-                "value": a.steps / pdt * world, "unit": out["unit"], "ms_per_step": pdt / a.steps * 1e3,
+                "value": 1e3 / pst["median"] * world, "unit": out["unit"], "ms_per_step": pst["median"],
                 "note": "Ghysels-Vanroose recurrence, outside the parity contract: one reduction point per trip"})
+        h.set_option("cg_variant", 0)
     if dist is not None:
         dist.barrier()
+    if rank == 0 and c2_single and fmt == capi.FMT_CSR_EXACT and not a.no_generic:
+        # the exact SpMV of the same matrix without any dictionary form, and with its rows randomly permuted
+        out["spmv"].update(generic_spmv_entries(h, capi, rp, col, val, n, nnz, xd, yd, a.spmv_reps))
     h.close()
     if rank == 0:
-        if world == 1 and not force_dist and not a.no_extra and N == 256:
+        if c2_single and not a.no_extra:
             # BASELINE.json configs[2] and configs[3] on the same GPU, as sub-objects (never `value`)
             del rp, col, val
             out["configs"] = other_configs(capi, matgen, S)

@@ -89,6 +89,10 @@ int orc_solve(int n, const int *row_ptr, const int *col, const double *val,
               const double *b, const double *x0, const orc_params *p,
               double *history, double *x_star, orc_result *out);
 
+/* Matrix Market text of a CRS matrix ("%%MatrixMarket matrix coordinate real general", 1-based, %.17g): the input file of
+ * the compiled reference for the CPU calibration leg of bench.py (io_funcs.hpp:125-289 reads it back).  0 = ok. */
+int orc_write_mtx(const char *path, int n_rows, int n_cols, const int *row_ptr, const int *col, const double *val);
+
 int orc_num_threads(void);
 /* 1 thread = bit-identical to the compiled reference at OMP_NUM_THREADS=1 */
 void orc_set_threads(int t);

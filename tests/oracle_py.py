@@ -166,6 +166,15 @@ def solve(rp, col, val, b, x0, solver, *, jacobi_mode=0, precond=0, max_iters=50
                 seconds=r.solve_seconds, all_values=hist[:r.residual_count + 1].copy())
 
 
+def write_mtx(path, rp, col, val, n_cols=None):
+    """Matrix Market text of a CRS matrix, same text as iterative_solvers_amd.matgen.write_mtx, ten times as fast"""
+    n = len(rp) - 1
+    rc = lib().orc_write_mtx(str(path).encode(), C.c_int(n), C.c_int(n if n_cols is None else n_cols),
+                             _p(_i32(rp)), _p(_i32(col)), _p(_f64(val)))
+    if rc != 0:
+        raise OSError(f"orc_write_mtx({path}) failed: {rc}")
+
+
 def num_threads():
     return lib().orc_num_threads()
 

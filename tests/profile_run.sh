@@ -8,7 +8,8 @@ rm -rf gpurun_out/$R      # (on the GPU box; gpurun MERGES results into the loca
                           # gpurun_out/$R before the call as well, or stale traces sit beside the new ones)
 mkdir -p gpurun_out/$R
 timeout -k 10 400 python3 bench.py > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -- python3 bench.py --no-cpu --no-extra > gpurun_out/$R/trace.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -- python3 bench.py --no-cpu --no-extra --no-generic > gpurun_out/$R/trace.log 2>&1 || exit 1
+export ITS_BENCH_NO_PERMUTED=1      # the counter passes also profile spmv_ellg_kernel on the C2 matrix (spmv.exact_generic)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d gpurun_out/$R/pmc_$c -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-extra --spmv-reps 5 > gpurun_out/$R/pmc_$c.log 2>&1 || exit 1
 done
