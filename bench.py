@@ -655,7 +655,6 @@ def main():
             out["opt_in"] = dict(out.get("opt_in") or {}, pipelined_cg={
                 "value": 1e3 / pst["median"] * world, "unit": out["unit"], "ms_per_step": pst["median"],
                 "note": "Ghysels-Vanroose recurrence, outside the parity contract: one reduction point per trip"})
-        h.set_option("cg_variant", 0)
     if dist is not None:
         dist.barrier()
     if rank == 0 and c2_single and fmt == capi.FMT_CSR_EXACT and not a.no_generic:

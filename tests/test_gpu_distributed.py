@@ -129,23 +129,25 @@ def test_rccl_world_one_matches_single_gpu():
     assert np.array_equal(hists[0][2], hists[1][2])
 
 
-def _periodic_z_laplacian(N, diag=7.0):
-    """7-pt stencil on an N^3 grid, periodic in z (SPD with diag > 6): the global matrix and the one-rank local
-    form whose wrap-around columns are halo entries [n, n + 2 N^2): first the copy of plane N-1, then of plane 0."""
-    n = N * N * N
-    idx = np.arange(n).reshape(N, N, N)                      # [z, y, x]
+def _periodic_z_laplacian(N, diag=7.0, NZ=None):
+    """7-pt stencil on an N x N x NZ grid (NZ = N by default), periodic in z (SPD with diag > 6): the global matrix and the
+    one-rank local form whose wrap-around columns are halo entries [n, n + 2 N^2): first the copy of plane NZ-1, then of
+    plane 0."""
+    NZ = N if NZ is None else NZ
+    n = N * N * NZ
+    idx = np.arange(n).reshape(NZ, N, N)                     # [z, y, x]
     rows, cols_g, cols_l, vals = [], [], [], []
     P = N * N
     for dz, dy, dx in ((-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0)):
-        z, y, x = np.meshgrid(np.arange(N), np.arange(N), np.arange(N), indexing="ij")
+        z, y, x = np.meshgrid(np.arange(NZ), np.arange(N), np.arange(N), indexing="ij")
         zz, yy, xx = z + dz, y + dy, x + dx
         ok = (yy >= 0) & (yy < N) & (xx >= 0) & (xx < N)
-        wrap_lo, wrap_hi = zz < 0, zz >= N
-        zg = zz % N
+        wrap_lo, wrap_hi = zz < 0, zz >= NZ
+        zg = zz % NZ
         g = idx[zg[ok], yy[ok], xx[ok]]
         l = g.copy()
         plane_pos = (yy * N + xx)[ok]
-        l[wrap_lo[ok]] = n + plane_pos[wrap_lo[ok]]          # copy of plane N-1
+        l[wrap_lo[ok]] = n + plane_pos[wrap_lo[ok]]          # copy of plane NZ-1
         l[wrap_hi[ok]] = n + P + plane_pos[wrap_hi[ok]]      # copy of plane 0
         rows.append(idx[ok]); cols_g.append(g); cols_l.append(l)
         vals.append(np.full(g.size, diag if (dz, dy, dx) == (0, 0, 0) else -1.0))
@@ -154,19 +156,21 @@ def _periodic_z_laplacian(N, diag=7.0):
         order = np.lexsort((c, rows))
         rp = np.zeros(n + 1, dtype=np.int32); np.add.at(rp, rows + 1, 1); rp = np.cumsum(rp).astype(np.int32)
         return rp, c[order].astype(np.int32), v[order]
-    send_idx = np.concatenate([idx[N - 1].ravel(), idx[0].ravel()]).astype(np.int32)
+    send_idx = np.concatenate([idx[NZ - 1].ravel(), idx[0].ravel()]).astype(np.int32)
     return n, to_crs(cg_), to_crs(cl_), send_idx
 
 
 @pytest.mark.parametrize("two_entries", [False, True])
 @pytest.mark.parametrize("overlap", [0, 1])
-def test_rccl_send_recv_loopback_on_one_gpu(overlap, two_entries):
+@pytest.mark.parametrize("N,NZ", [(12, 12), (64, 8)])
+def test_rccl_send_recv_loopback_on_one_gpu(overlap, two_entries, N, NZ):
     """The RCCL halo exchange (pack kernel -> grouped ncclSend/ncclRecv on the side stream -> boundary SpMV after
     the halo event) run for real on ONE GPU: a one-rank world whose only neighbour is itself, carrying the
-    wrap-around planes of a z-periodic Laplacian.  Checked against the same system as one global matrix."""
+    wrap-around planes of a z-periodic Laplacian.  Checked against the same system as one global matrix.
+    (64, 8): the small analogue of a rank's slab of BASELINE configs[4] — 512 x 512 x 64 of the 512^3 grid: few wide
+    planes; a plane is 8 row blocks of the ELL kernel, so the period work map is on, as it is at full size)."""
     import ctypes as C
-    N = 12
-    n, (rpg, colg, valg), (rpl, coll, vall), send_idx = _periodic_z_laplacian(N)
+    n, (rpg, colg, valg), (rpl, coll, vall), send_idx = _periodic_z_laplacian(N, NZ=NZ)
     P = N * N
     hists = []
     for loop in (False, True):
@@ -198,6 +202,84 @@ def test_rccl_send_recv_loopback_on_one_gpu(overlap, two_entries):
     a, b = np.array(hists[0][1]), np.array(hists[1][1])
     assert np.all(np.abs(a - b) <= 1e-11 * np.maximum(a, 1e-3 * a[0]))
     assert np.max(np.abs(hists[0][2] - hists[1][2])) <= 1e-11 * np.max(np.abs(hists[0][2]))
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_rccl_colored_sweep_exchange_loopback_on_one_gpu(overlap):
+    """The RCCL branch of the per-colour exchange (its_dist_exchange: grouped ncclSend / ncclRecv of one colour's segment
+    of the send list) on ONE GPU: a one-rank world that is its own neighbour, Gauss-Seidel in global
+    multicolour (red-black) order on a z-periodic Laplacian whose wrap-around columns are halo entries.  After every
+    colour the halo copies are refreshed through RCCL, so the sweep is the natural-order sweep on the colour-permuted
+    global matrix B = Q A Q^T: the iterate must equal the oracle's on B bit for bit, histories to the usual bar."""
+    import ctypes as C
+    N, NZ = 10, 8                                            # even NZ: parity colouring is proper across the z wrap
+    n, (rpg, colg, valg), _, _ = _periodic_z_laplacian(N, NZ=NZ)
+    z, y, x = np.meshgrid(np.arange(NZ), np.arange(N), np.arange(N), indexing="ij")
+    color = ((x + y + z) % 2).ravel()
+    perm = np.concatenate([np.nonzero(color == 0)[0], np.nonzero(color == 1)[0]]).astype(np.int32)   # B-index -> original row
+    rpB, colB, valB = capi.permute_crs(rpg, colg, valg, perm)
+    inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+    n_red = int(np.count_nonzero(color == 0))
+    rowsB = np.repeat(np.arange(n), np.diff(rpB))
+    # wrap-around entries: original row and column in planes 0 / NZ-1 of different z
+    zo = perm // (N * N)
+    wrap = (np.abs(zo[rowsB] - zo[colB]) == NZ - 1)
+    S = np.unique(colB[wrap]).astype(np.int64)               # B-rows whose values travel, ascending = colour by colour
+    pos = np.full(n, -1, np.int64); pos[S] = np.arange(len(S))
+    coll = colB.astype(np.int64).copy(); coll[wrap] = n + pos[colB[wrap]]
+    lower, upper, dg = colB < rowsB, colB > rowsB, colB == rowsB
+
+    def sub(mask):
+        cnt = np.bincount(rowsB[mask], minlength=n)
+        return np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), coll[mask].astype(np.int32), valB[mask]
+    diag = np.zeros(n); diag[rowsB[dg]] = valB[dg]
+    orc.set_threads(1)
+    trips = 20
+    ref = orc.solve(rpB, colB, valB, np.ones(n), np.ones(n), orc.GAUSS_SEIDEL, fixed_iters=trips, max_iters=trips)
+    h = capi.Handle(0)
+    try:
+        h.set_option("dist_overlap", overlap)
+        ids = C.create_string_buffer(256)
+        h.check(h.L.its_comm_unique_id(ids), "its_comm_unique_id")
+        h.check(h.L.its_comm_unique_id(C.byref(ids, 128)), "its_comm_unique_id")
+        h.check(h.L.its_comm_init(h.h, 0, 1, ids), "its_comm_init")
+        nc = n + len(S)
+        h.upload_crs(rpB, coll.astype(np.int32), valB, capi.MAT_A, capi.FMT_CSR_EXACT, n_cols=nc)
+        h.upload_crs(*sub(lower), capi.MAT_L, capi.FMT_CSR_EXACT, n_cols=nc)
+        h.upload_crs(*sub(upper), capi.MAT_U, capi.FMT_CSR_EXACT, n_cols=nc)
+        arr = lambda v: np.ascontiguousarray(v, dtype=np.int32)          # noqa: E731
+        nbr, off, si = arr([0]), arr([0, len(S)]), arr(S)
+        h.check(h.L.its_dist_setup(h.h, 1, nbr.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                   si.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p)), "its_dist_setup")
+        s_red = int(np.count_nonzero(S < n_red))
+        cptr, sco = arr([0, n_red, n]), arr([[0, s_red, len(S)]])
+        h.check(h.L.its_dist_set_colors(h.h, 2, cptr.ctypes.data_as(C.c_void_p), sco.ctypes.data_as(C.c_void_p),
+                                        sco.ctypes.data_as(C.c_void_p)), "its_dist_set_colors")
+        h.upload_vectors(diag, np.ones(n), np.ones(n))
+        h.init_residual()
+        h.solver_setup(capi.GAUSS_SEIDEL, gs_order=capi.GS_MULTICOLOR)
+        hist = np.array([h.iterate(i) for i in range(trips)])
+        xB = h.download_x(n, trips)
+    finally:
+        h.close()
+    exp = ref["all_values"][:trips]
+    assert np.all(np.abs(hist[:len(exp)] - exp) <= 1e-10 * np.maximum(exp, 1e-2 * ref["r0_two"]))
+    assert np.array_equal(xB, ref["x_star"])                 # no reduction touches a Gauss-Seidel iterate
+
+
+def test_bench_global_grid_host_transport():
+    """`bench.py --gpus 2 --global-grid 32`: the ranks share ONE 32^3 grid (the configs[4] mode: 512^3 over 8 ranks),
+    16 planes of 32^2 each, through the HOST rehearsal transport on the one-GPU box."""
+    env = dict(os.environ, ITS_BENCH_TRANSPORT="host", ITS_BENCH_SPAWN_TIMEOUT="100")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--global-grid", "32", "--no-cpu"], env=env, capture_output=True, text=True, timeout=115)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert out["n_gpus"] == 2 and out["config"]["rows_per_gpu"] == 32 * 32 * 16 and out["config"]["grid_mode"] == "global-grid"
+    assert "32^3 grid shared by 2 z-slabs of 16 planes" in out["config"]["workload"] and out["scaling"] == "strong"
+    assert out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"] and out["regions"] == 5
 
 
 def test_bench_spawns_its_own_ranks_host_transport():
