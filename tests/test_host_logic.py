@@ -4,6 +4,8 @@ declares (no compute calls: there is no GPU here)."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -215,3 +217,12 @@ def test_bench_spawn_reports_a_failing_rank(tmp_path):
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert "rank" in p.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="container-only: needs the reference's sources")
+def test_integration_binding_compiles_into_the_reference_and_links():
+    """INTEGRATION.md's USE_MI355X binding inserted by line number into the reference's solver.hpp / utility_funcs.hpp,
+    its main.cpp compiled unchanged, linked against libits_hip.so (oracle/build_integrated.py; -O0: compile and link only)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_integration.py"), "--opt=-O0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert "linked against libits_hip.so" in p.stdout
