@@ -226,3 +226,64 @@ def test_spmv_powerlaw_2m_panel_image_bit_exact(gpu_handle, powerlaw2m):
     finally:
         h.set_option("spmv_panel", 1)
         h.dev_free(px); h.dev_free(py)
+
+
+def test_zz_powerlaw_10m_the_config_itself():
+    """BASELINE configs[3] at ITS size — the 10 M-row power-law matrix bench.py times (84 M entries, longest row 8192) —
+    checked, not only timed: exact SpMV == oracle; Jacobi (correct sweep, one fused pass over A per
+    trip) 3 trips and multicolour Gauss-Seidel 2 trips: iterate == oracle bit for bit (per-row in-order chains), recorded
+    norms to 1e-10; kernel names asserted.  Last in this file: it holds 3 GB of host arrays and takes about half a minute."""
+    rp, col, val = matgen.powerlaw(10_000_000)
+    n = len(rp) - 1
+    assert n == 10_000_000 and int(np.diff(rp).max()) == 8192
+    b = np.ones(n)
+    x = np.random.default_rng(21).uniform(-1, 1, n)
+    orc.set_threads(min(16, orc.num_threads()))
+    try:
+        ref_y = orc.spmv(rp, col, val, x)
+        h = capi.Handle(0)
+        try:
+            h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+            assert h.spmv_kernel_info(capi.MAT_A)[0] == "spmv_panel_kernel"
+            assert np.array_equal(h.spmv_host(x, n, capi.MAT_A, capi.FMT_CSR_EXACT), ref_y)
+        finally:
+            h.close()
+        del ref_y
+        # ---- Jacobi, 3 trips from x0 = 0
+        trips = 3
+        ref = orc.solve(rp, col, val, b, np.zeros(n), orc.JACOBI, jacobi_mode=1, fixed_iters=trips, max_iters=trips)
+        args = S.Args("jacobi", S.LoopParams(max_iters=10**9, tol=0.0))
+        sol = S.Solver("jacobi", device=0, jacobi_mode=1)
+        try:
+            S.preprocessing_crs(args, sol, rp, col, val, b, np.zeros(n))
+            assert sol.handle.spmv_kernel_info(capi.MAT_A)[0] == "spmv_panel_kernel"
+            got = np.array([sol.handle.iterate(it) for it in range(trips)])
+            xs = sol.save_x_star(trips).copy()
+        finally:
+            sol.handle.close()
+        want = ref["all_values"][:trips]
+        assert np.all(np.abs(got - want) <= 1e-10 * want), np.abs(got - want) / want
+        assert np.array_equal(xs, ref["x_star"])
+        del ref, xs
+        # ---- multicolour Gauss-Seidel, 2 trips: the oracle's natural-order sweep of the permuted matrix
+        trips = 2
+        perm, nc = capi.multicolor_order(rp, col)
+        rpp, cp, vp = capi.permute_crs(rp, col, val, perm)
+        ref = orc.solve(rpp, cp, vp, b, b.copy(), orc.GAUSS_SEIDEL, fixed_iters=trips, max_iters=trips)
+        del rpp, cp, vp
+        args = S.Args("gauss-seidel", S.LoopParams(max_iters=10**9, tol=0.0))
+        sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_MULTICOLOR)
+        try:
+            S.preprocessing_crs(args, sol, rp, col, val, b, b.copy())
+            assert sol.n_colors == nc and nc <= 32
+            assert sol.handle.spmv_kernel_info(capi.MAT_A)[0] == "spmv_panel_kernel"
+            got = np.array([sol.handle.iterate(it) for it in range(trips)])
+            xs = sol.save_x_star(trips).copy()
+        finally:
+            sol.handle.close()
+        want = ref["all_values"][:trips]
+        assert np.all(np.abs(got - want) <= 1e-10 * want), np.abs(got - want) / want
+        x_ref = np.empty(n); x_ref[perm] = ref["x_star"]
+        assert np.array_equal(xs, x_ref)
+    finally:
+        orc.set_threads(1)
