@@ -252,6 +252,10 @@ int its_permute_crs(int n, const int *row_ptr, const int *col, const double *val
 /* rank 0 makes an id (128 bytes, RCCL ncclUniqueId); the caller's control plane hands TWO ids
  * (halo communicator, reduction communicator) to every rank */
 int its_comm_unique_id(void *id128);
+/* Blocks until every rank has joined, at most ITS_COMM_TIMEOUT_S (default 180) seconds.  After ITS_ECOMM from a time-out
+ * the handle is unusable for row-partitioned runs (a later its_comm_init / its_dist_setup on it returns ITS_ESTATE; the
+ * communicators the late peers may still complete are aborted by the library): the rank must exit non-zero and the job be
+ * restarted with FRESH processes — never re-exec a process that has initialised the GPU. */
 int its_comm_init(its_handle *h, int rank, int world, const void *ids256);
 /* Test transport: halo data and scalars are staged through the host and exchanged by the
  * caller's callbacks (return 0 on success), so several ranks can share one GPU.

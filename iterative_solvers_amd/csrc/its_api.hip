@@ -268,7 +268,9 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     if (!h || which < 0 || which > 2 || n_rows < 0 || nnz < 0 || !row_ptr) return ITS_EINVAL;
     if (nnz > 0 && (!col || !val)) FAIL(h, ITS_EINVAL, "null col/val");
     if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) FAIL(h, ITS_EINVAL, "row_ptr[0] != 0 or row_ptr[n] != nnz");
-    if (nnz > INT32_MAX - 16) FAIL(h, ITS_EUNSUPPORTED, "nnz exceeds int32 offsets (sparse_matrix.hpp:20-27)");
+    // (the walks of long rows prefetch up to 3 chunks — a few thousand entries — past the entry they work on with 32-bit
+    // indices, its_panel.hip: the limit keeps those sums inside int32)
+    if (nnz > INT32_MAX - 65536) FAIL(h, ITS_EUNSUPPORTED, "nnz exceeds int32 offsets (sparse_matrix.hpp:20-27; limit 2^31 - 65536 entries)");
     HIPCHK(h, hipSetDevice(h->device));
     PhaseTimer pt(which == ITS_MAT_A ? "upload A" : which == ITS_MAT_L ? "upload L" : "upload U");
     // validate what the kernels assume BEFORE anything of the old matrix is given up: monotone row_ptr, columns
@@ -463,6 +465,14 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         h->L_rp.assign(row_ptr, row_ptr + n_rows + 1);
         h->L_maxcol.assign((size_t)std::max(n_rows, 1), -1);
         its_host::row_maxcol(n_rows, row_ptr, col, n_rows, h->L_maxcol.data());
+        // columns at or beyond the rows (halo columns of a row partition) are left out of L_maxcol; remember whether
+        // there are any: outside a distributed run they make L not strictly lower
+        h->L_has_halo_cols = false;
+        if (n_cols > n_rows) {
+            std::vector<int> any((size_t)std::max(n_rows, 1), -1);
+            its_host::row_maxcol(n_rows, row_ptr, col, n_cols, any.data());
+            for (int i = 0; i < n_rows && !h->L_has_halo_cols; ++i) h->L_has_halo_cols = any[i] >= n_rows;
+        }
         pt.lap("row structure of L for the sweep schedule");
     }
     h->have[which] = true;
@@ -969,6 +979,7 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
                     if (h->L_maxcol[i] >= cp[c]) FAIL(h, ITS_EINVAL, "crs_L: a row reads an owned row of its own or a later colour");
             rc = build_levels(h, n, cp, nc);
         } else {
+            if (h->L_has_halo_cols) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular (it has columns beyond its rows and no row partition is set up)");
             for (int i = 0; i < n; ++i)
                 if (h->L_maxcol[i] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
             rc = build_levels(h, n);
@@ -1789,6 +1800,7 @@ extern "C" int its_spltsv(its_handle *h, double *x_dev, const double *rhs_dev)
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->level_rows) {
         const int n = h->mat[ITS_MAT_L].n_rows;
+        if (h->L_has_halo_cols && !its_dist_active(h)) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular (it has columns beyond its rows and no row partition is set up)");
         for (int i = 0; i < n; ++i)
             if (h->L_maxcol[i] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
         int rc = build_levels(h, n);

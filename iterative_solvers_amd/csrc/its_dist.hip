@@ -83,7 +83,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void pack_kernel(const double *__restric
     if (i < n) out[i] = x[idx[i]];
 }
 
-int its_dist_active(const its_handle *h) { return h->dist && h->dist->transport != 0 && h->dist->plan_ready; }
+int its_dist_active(const its_handle *h) { return h->dist && h->dist->transport > 0 && h->dist->plan_ready; }
 
 void its_dist_destroy(its_handle *h)
 {
@@ -137,6 +137,7 @@ extern "C" int its_comm_init(its_handle *h, int rank, int world, const void *ids
     int rc = ensure_plan(h);
     if (rc) return rc;
     DistPlan *d = h->dist;
+    if (d->transport < 0) FAIL(h, ITS_ESTATE, "an earlier its_comm_init on this handle timed out: the handle cannot join a row-partitioned run (start a fresh process)");
     if (d->transport != 0) FAIL(h, ITS_ESTATE, "communicator already initialised");
     ncclUniqueId id0, id1;
     memcpy(&id0, ids256, 128);
@@ -150,8 +151,8 @@ extern "C" int its_comm_init(its_handle *h, int rank, int world, const void *ids
     int dev_count = 0;
     HIPCHK(h, hipGetDeviceCount(&dev_count));
     const int timeout_s = std::max(1, env_seconds("ITS_COMM_TIMEOUT_S", 180));
-    struct InitState { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r0 = ncclSuccess, r1 = ncclSuccess;
-                       ncclComm_t c0 = nullptr, c1 = nullptr; };
+    struct InitState { std::mutex mu; std::condition_variable cv; bool done = false, abandoned = false;
+                       ncclResult_t r0 = ncclSuccess, r1 = ncclSuccess; ncclComm_t c0 = nullptr, c1 = nullptr; };
     auto st = std::make_shared<InitState>();
     const int device = h->device;
     std::thread([st, id0, id1, world, rank, device]() {
@@ -161,16 +162,26 @@ extern "C" int its_comm_init(its_handle *h, int rank, int world, const void *ids
             r0 = ncclCommInitRank(&c0, world, id0, rank);
             r1 = r0 == ncclSuccess ? ncclCommInitRank(&c1, world, id1, rank) : r0;
         }
-        std::lock_guard<std::mutex> lk(st->mu);
-        st->r0 = r0; st->r1 = r1; st->c0 = c0; st->c1 = c1; st->done = true;
-        st->cv.notify_all();
+        bool abandoned;
+        {
+            std::lock_guard<std::mutex> lk(st->mu);
+            abandoned = st->abandoned;
+            if (!abandoned) { st->r0 = r0; st->r1 = r1; st->c0 = c0; st->c1 = c1; }
+            st->done = true;
+            st->cv.notify_all();
+        }
+        // the waiter gave up (time-out) before the peers arrived: nobody will ever use or free these communicators
+        if (abandoned) { if (c0) (void)ncclCommAbort(c0); if (c1) (void)ncclCommAbort(c1); }
     }).detach();
     {
         std::unique_lock<std::mutex> lk(st->mu);
         if (!st->cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return st->done; })) {
-            char msg[256];
+            char msg[512];
             snprintf(msg, sizeof msg, "ncclCommInitRank: rank %d of %d on device %d (of %d visible) did not complete within %d s "
-                     "(a peer rank missing, or two ranks on one GPU?)", rank, world, device, dev_count, timeout_s);
+                     "(a peer rank missing, or two ranks on one GPU?); this handle cannot join a row-partitioned run any more: exit "
+                     "the rank (non-zero) and start a fresh process", rank, world, device, dev_count, timeout_s);
+            st->abandoned = true;                  // the helper thread aborts whatever it obtains later
+            d->transport = -1;                     // a second its_comm_init on this handle is refused ("already initialised")
             FAIL(h, ITS_ECOMM, msg);
         }
         if (st->r0 != ncclSuccess) FAIL(h, ITS_ECOMM, std::string("ncclCommInitRank (halo): ") + ncclGetErrorString(st->r0));
@@ -199,7 +210,7 @@ extern "C" int its_dist_setup(its_handle *h, int n_nbr, const int *nbr, const in
 {
     if (!h || n_nbr < 0 || (n_nbr > 0 && (!nbr || !send_off || !recv_off))) return ITS_EINVAL;
     if (n_nbr > 0 && send_off[n_nbr] > 0 && !send_idx) FAIL(h, ITS_EINVAL, "send_idx is null but send_off lists entries to send");
-    if (!h->dist || h->dist->transport == 0) FAIL(h, ITS_ESTATE, "its_comm_init first");
+    if (!h->dist || h->dist->transport <= 0) FAIL(h, ITS_ESTATE, "its_comm_init first (and it must have succeeded)");
     if (!h->have[ITS_MAT_A]) FAIL(h, ITS_ESTATE, "upload the local matrix first");
     HIPCHK(h, hipSetDevice(h->device));
     DistPlan *d = h->dist;

@@ -105,6 +105,7 @@ struct its_handle {
     // host image of crs_L's row structure, kept at upload so that the schedule needs no copy back from the device:
     // row_ptr and, per row, the largest owned column (-1: none)
     std::vector<int> L_rp, L_maxcol;
+    bool L_has_halo_cols = false;                // crs_L has columns >= its row count (legal only in a row-partitioned run)
     // level-ordered copy of L for scattered levels of short rows (natural-order sweeps of stencils), its_kernels.hip
     int *sw_col = nullptr; double *sw_val = nullptr, *sw_D = nullptr;
     int sw_w = 0;                         // 0: not built

@@ -298,3 +298,32 @@ def test_bench_spawns_its_own_ranks_host_transport():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     assert out["metric"] == "cg_iters_per_sec" and out["value"] > 0 and out["jacobi"]["value"] > 0
+
+
+def test_comm_init_timeout_leaves_the_handle_refusing_a_second_try():
+    """A rank whose peer never arrives: its_comm_init gives up after ITS_COMM_TIMEOUT_S with ITS_ECOMM and a message that
+    names rank and device; the handle then refuses another its_comm_init and its_dist_setup (what a caller may
+    do after that error is documented in include/its_hip.h — exit and restart with fresh processes).  Run in a child
+    process: the helper thread is still inside the RCCL bootstrap when the process ends."""
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from iterative_solvers_amd import capi
+h = capi.Handle(0)
+ids = C.create_string_buffer(256)
+h.check(h.L.its_comm_unique_id(ids), "id"); h.check(h.L.its_comm_unique_id(C.byref(ids, 128)), "id")
+rc = h.L.its_comm_init(h.h, 0, 2, ids)                      # world of 2, rank 1 never joins
+msg = h.L.its_last_error(h.h).decode()
+rc2 = h.L.its_comm_init(h.h, 0, 2, ids)
+msg2 = h.L.its_last_error(h.h).decode()
+rc3 = h.L.its_dist_setup(h.h, 0, None, None, None, None)
+print("ITSRC", rc, rc2, rc3); print("ITSMSG1", msg); print("ITSMSG2", msg2)
+sys.stdout.flush()
+import os; os._exit(0)
+''' % os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ITS_COMM_TIMEOUT_S="3"), capture_output=True, text=True, timeout=100)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rcs = [ln for ln in p.stdout.splitlines() if ln.startswith("ITSRC")][0].split()[1:]
+    assert int(rcs[0]) < 0 and int(rcs[1]) < 0 and int(rcs[2]) < 0, p.stdout
+    assert "did not complete within 3 s" in p.stdout and "fresh process" in p.stdout
+    assert "timed out" in [ln for ln in p.stdout.splitlines() if ln.startswith("ITSMSG2")][0]

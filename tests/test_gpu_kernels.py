@@ -111,6 +111,25 @@ def test_spmv_rejects_bad_input(gpu_handle):
         gpu_handle.upload_crs(np.array([0, 2, 1], np.int32), np.array([0, 1], np.int32), np.ones(2))
 
 
+def test_sweep_rejects_a_lower_triangle_with_columns_beyond_its_rows():
+    """crs_L with n_cols > n_rows and an entry in [n_rows, n_cols) is only legal in a row-partitioned run (halo columns of
+    earlier colours): on one GPU the sweep would read past the iterate, so the schedule refuses it."""
+    h = capi.Handle(0)
+    try:
+        n = 6
+        rp = np.array([0, 0, 1, 2, 3, 4, 5], np.int32)
+        h.upload_crs(np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.full(n, 2.0), capi.MAT_A)
+        h.upload_vectors(np.full(n, 2.0), np.ones(n), np.ones(n))
+        xd = h.to_dev(np.zeros(n)); rd = h.to_dev(np.ones(n))
+        h.upload_crs(rp, np.array([0, 1, 2, 3, 4], np.int32), np.ones(5), capi.MAT_L, n_cols=n + 2)     # fine: strictly lower
+        h.spltsv(xd, rd)
+        h.upload_crs(rp, np.array([0, 1, n + 1, 3, 4], np.int32), np.ones(5), capi.MAT_L, n_cols=n + 2)  # row 3 reads column 7
+        with pytest.raises(capi.ItsError, match="strictly lower"):
+            h.spltsv(xd, rd)
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 4097, 100001, 1 << 20])
 def test_blas1(gpu_handle, n):
     h = gpu_handle
