@@ -221,6 +221,13 @@ int its_ell_info(its_handle *h, int which, int *kind, int *width, int64_t *index
 /* after its_solver_setup(ITS_GMRES): workgroups of the persistent Gram-Schmidt launch ("gmres_persist"; 0 = the trips
  * run one launch per basis vector) and how many trips had to be repeated that way because the launch gave up */
 int its_gmres_info(its_handle *h, int *persist_grid, int *fallbacks);
+/* after its_solver_setup(ITS_GAUSS_SEIDEL): prefix_ready = 1 when the trips run with option "gs_prefix" (default 1): the
+ * set-up has verified on the device that every row of A is [its row of crs_L | one diagonal entry | its row of crs_U],
+ * bit for bit and in that order (what gauss_seidel.hpp:249-630 builds), so the chain of the recorded residual b - A x_new
+ * (utility_funcs.hpp:444-447) starts with the chain the sweep (kernels.hpp:460-472) has just run: the sweep leaves its
+ * sums behind and the residual pass walks the rows from the diagonal on only (nnz_du entries instead of nnz of A), same
+ * bits.  kernel = the family that pass runs on (as its_spmv_kernel_info), "" when prefix_ready = 0 */
+int its_gs_info(its_handle *h, int *prefix_ready, int64_t *nnz_du, char *kernel, int kernel_cap);
 
 /* ---- Gauss-Seidel ordering helpers (host only, no GPU needed) -------------------------
  * methods/gauss_seidel.hpp sweeps in natural order; its_solver_setup schedules that sweep by

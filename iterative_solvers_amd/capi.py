@@ -64,6 +64,7 @@ SIGNATURES = {
     "its_spmv_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, _c_i64_p]),
     "its_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_int_p, _c_dbl_p, _c_int_p]),
     "its_gmres_info": (C.c_int, [C.c_void_p, _c_int_p, _c_int_p]),
+    "its_gs_info": (C.c_int, [C.c_void_p, _c_int_p, C.POINTER(C.c_int64), C.c_char_p, C.c_int]),
     "its_ell_info": (C.c_int, [C.c_void_p, C.c_int, _c_int_p, _c_int_p, C.POINTER(C.c_int64), _c_int_p]),
     "its_extract_diag": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "its_split_lu": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
@@ -291,6 +292,13 @@ class Handle:
         g, f = C.c_int(), C.c_int()
         self.check(self.L.its_gmres_info(self.h, C.byref(g), C.byref(f)), "its_gmres_info")
         return {"persist_grid": g.value, "fallbacks": f.value}
+
+    def gs_info(self):
+        """Gauss-Seidel trips: is the "gs_prefix" form active (the residual pass walks D + U only), its entries, its kernel."""
+        r, nz = C.c_int(), C.c_int64()
+        buf = C.create_string_buffer(64)
+        self.check(self.L.its_gs_info(self.h, C.byref(r), C.byref(nz), buf, 64), "its_gs_info")
+        return {"prefix_ready": bool(r.value), "nnz_du": nz.value, "kernel": buf.value.decode()}
 
     # ---- device memory
     def dev_alloc(self, nbytes: int) -> int:

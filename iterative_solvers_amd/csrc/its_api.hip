@@ -265,14 +265,14 @@ static int build_sell(its_handle *h, CsrDev &A, int n, const int *rp, const int 
 int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64_t nnz,
                          const int *row_ptr, const int *col, const double *val, int format)
 {
-    if (!h || which < 0 || which > 2 || n_rows < 0 || nnz < 0 || !row_ptr) return ITS_EINVAL;
+    if (!h || which < 0 || which > ITS_MAT_DU || n_rows < 0 || nnz < 0 || !row_ptr) return ITS_EINVAL;
     if (nnz > 0 && (!col || !val)) FAIL(h, ITS_EINVAL, "null col/val");
     if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) FAIL(h, ITS_EINVAL, "row_ptr[0] != 0 or row_ptr[n] != nnz");
     // (the walks of long rows prefetch up to 3 chunks — a few thousand entries — past the entry they work on with 32-bit
     // indices, its_panel.hip: the limit keeps those sums inside int32)
     if (nnz > INT32_MAX - 65536) FAIL(h, ITS_EUNSUPPORTED, "nnz exceeds int32 offsets (sparse_matrix.hpp:20-27; limit 2^31 - 65536 entries)");
     HIPCHK(h, hipSetDevice(h->device));
-    PhaseTimer pt(which == ITS_MAT_A ? "upload A" : which == ITS_MAT_L ? "upload L" : "upload U");
+    PhaseTimer pt(which == ITS_MAT_A ? "upload A" : which == ITS_MAT_L ? "upload L" : which == ITS_MAT_U ? "upload U" : "image of D + U");
     // validate what the kernels assume BEFORE anything of the old matrix is given up: monotone row_ptr, columns
     // inside [0, n_cols).  A rejected upload leaves the handle as it was.
     {
@@ -286,6 +286,10 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     // the slot empty (have[which] false), never half-built
     h->have[which] = false;
     h->setup_done = false; h->ahead = false;
+    if (which != ITS_MAT_DU) {                    // the image of D + U describes the old A / L / U
+        h->gs_prefix_ready = false; h->have[ITS_MAT_DU] = false;
+        free_csr(h->mat[ITS_MAT_DU]);
+    }
     if (which == ITS_MAT_A) h->residual_done = false;
     if (which == ITS_MAT_L) {                     // the sweep schedule describes the old L
         dfree(h->level_rows); dfree(h->sweep_desc); free_level_ell(h);
@@ -449,7 +453,7 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         }
     }
     pt.lap("ELL image");
-    if (which == ITS_MAT_A || which == ITS_MAT_U) {
+    if (which == ITS_MAT_A || which == ITS_MAT_U || which == ITS_MAT_DU) {
         // column-panel blocked image for large irregular matrices (its_panel.hip); crs_U for the b - U x pass of GS
         // (the image is an extra: when it cannot be built — its 12 bytes per entry or the sort's 24 do not fit — the matrix
         // stays on the irregular-row kernel)
@@ -485,6 +489,7 @@ extern "C" int its_upload_crs(its_handle *h, int which, int n_rows, int n_cols, 
 {
     if (!h) return ITS_EINVAL;
     if (format < ITS_FMT_CSR_EXACT || format > ITS_FMT_MIXED) FAIL(h, ITS_EINVAL, "unknown format");
+    if (which < ITS_MAT_A || which > ITS_MAT_U) return ITS_EINVAL;
     int rc = its_upload_csr_local(h, which, n_rows, n_cols, nnz, row_ptr, col, val, format);
     if (rc == ITS_OK && which == ITS_MAT_A) { h->n = n_rows; h->n_ext = n_cols; }
     return rc;
@@ -591,6 +596,12 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->ahead = false;
         return ITS_OK;
     }
+    if (!strcmp(name, "gs_prefix")) {
+        if (value < 0 || value > 2) FAIL(h, ITS_EINVAL, "gs_prefix: 0 (off), 1 (where it pays: irregular matrices) or 2 (wherever it applies)");
+        if (h->setup_done && h->solver == ITS_GAUSS_SEIDEL && value != h->gs_prefix) FAIL(h, ITS_ESTATE, "set gs_prefix before its_solver_setup");
+        h->gs_prefix = value;
+        return ITS_OK;
+    }
     if (!strcmp(name, "fused_residual")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "fused_residual: 0 or 1");
         h->fused_residual = value;
@@ -635,6 +646,20 @@ extern "C" int its_gmres_info(its_handle *h, int *persist_grid, int *fallbacks)
     if (!h) return ITS_EINVAL;
     if (persist_grid) *persist_grid = h->mgs_grid;
     if (fallbacks) *fallbacks = h->mgs_fallbacks;
+    return ITS_OK;
+}
+
+extern "C" int its_gs_info(its_handle *h, int *prefix_ready, int64_t *nnz_du, char *kernel, int kernel_cap)
+{
+    if (!h) return ITS_EINVAL;
+    const bool on = h->gs_prefix_ready && h->have[ITS_MAT_DU];
+    if (prefix_ready) *prefix_ready = on ? 1 : 0;
+    if (nnz_du) *nnz_du = on ? h->mat[ITS_MAT_DU].nnz : 0;
+    if (kernel && kernel_cap > 0) {
+        SpmvArgs a;
+        const char *nm = on ? spmv_exact_kernel_name(h->mat[ITS_MAT_DU], a, EPI_GS_FUSED, nullptr) : "";
+        snprintf(kernel, (size_t)kernel_cap, "%s", nm);
+    }
     return ITS_OK;
 }
 
@@ -913,8 +938,92 @@ static int build_levels(its_handle *h, int n, const int *given_ptr = nullptr, in
     return ITS_OK;
 }
 
-// forward solve (D+L) x = rhs, level by level (kernels.hpp:451-473); x may alias rhs
-static int sweep(its_handle *h, double *x, const double *rhs, int first_level = 0)
+// ---------------------------------------------------------------------------------------
+// Gauss-Seidel, option "gs_prefix" (its_handle.h): is every row of A its row of crs_L, then ONE diagonal entry, then its
+// row of crs_U — entry for entry, bitwise, in that order?  (gauss_seidel.hpp:249-630 builds crs_L / crs_U that way from a
+// column-sorted A; nothing is assumed, everything compared.)  Then the sweep's chain over L is the residual chain's
+// prefix.  One lane per row; flags[0] |= 1 where a row differs; diag[row] = A's diagonal entry.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ITS_BLOCK) void gs_prefix_check_kernel(
+    int n, const int *__restrict__ a_rp, const int *__restrict__ a_col, const double *__restrict__ a_val,
+    const int *__restrict__ l_rp, const int *__restrict__ l_col, const double *__restrict__ l_val,
+    const int *__restrict__ u_rp, const int *__restrict__ u_col, const double *__restrict__ u_val,
+    double *__restrict__ diag, int *__restrict__ flags)
+{
+    const int row = blockIdx.x * ITS_BLOCK + threadIdx.x;
+    if (row >= n) return;
+    const int a0 = a_rp[row], a1 = a_rp[row + 1], l0 = l_rp[row], l1 = l_rp[row + 1], u0 = u_rp[row], u1 = u_rp[row + 1];
+    bool ok = a1 - a0 == (l1 - l0) + 1 + (u1 - u0);
+    double dg = 0.0;
+    if (ok) {
+        int p = a0;
+        for (int k = l0; k < l1 && ok; ++k, ++p)
+            ok = a_col[p] == l_col[k] && a_col[p] < row && __double_as_longlong(a_val[p]) == __double_as_longlong(l_val[k]);
+        ok = ok && a_col[p] == row;
+        dg = a_val[p]; ++p;
+        for (int k = u0; k < u1 && ok; ++k, ++p)
+            ok = a_col[p] == u_col[k] && a_col[p] > row && __double_as_longlong(a_val[p]) == __double_as_longlong(u_val[k]);
+    }
+    diag[row] = dg;
+    if (!ok) atomicOr(flags, 1);
+}
+
+int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64_t nnz,
+                         const int *row_ptr, const int *col, const double *val, int format);
+
+// Builds mat[ITS_MAT_DU] when the check above passes; leaves gs_prefix_ready false (and the trips on the pass over A)
+// in every other case.  Never fails the set-up: the image is an extra.
+static int build_gs_prefix(its_handle *h)
+{
+    h->gs_prefix_ready = false; h->have[ITS_MAT_DU] = false;
+    free_csr(h->mat[ITS_MAT_DU]);
+    static const bool env_off = getenv("ITS_GS_PREFIX") && atoi(getenv("ITS_GS_PREFIX")) == 0;
+    if (!h->gs_prefix || env_off || !h->fused_residual || its_dist_active(h)) return ITS_OK;
+    if (!h->have[ITS_MAT_A] || !h->have[ITS_MAT_L] || !h->have[ITS_MAT_U] || !h->D) return ITS_OK;
+    const CsrDev &A = h->mat[ITS_MAT_A], &L = h->mat[ITS_MAT_L], &U = h->mat[ITS_MAT_U];
+    const int n = h->n;
+    if (n < 1 || A.n_rows != n || A.n_cols != n || L.n_rows != n || U.n_rows != n || A.nnz != L.nnz + U.nnz + n) return ITS_OK;
+    // Where it pays (measured, ms per trip, off -> on).  Irregular matrices, whose passes are bound by their gathers: power-law
+    // 10 M rows, multicolour, 2.48 -> 1.83; 200 000 rows 0.270 -> 0.257 (natural order 0.382 -> 0.374).  Stencils: NOT — in
+    // red-black order D + U has rows of 7 entries and rows of 1, no ELL image, and the pass lands on the CRS stream kernel
+    // (7-pt 256^3 0.444 -> 0.518, 27-pt 128^3 0.217 -> 0.221); in natural order the sweep's levels are latency-bound
+    // launches and the second store per row costs them more than the shorter pass saves (256^3: 3.62 -> 3.87, 2-D 256^2:
+    // 0.391 -> 0.422).  Option value 1 therefore takes the irregular class only; 2 forces the form wherever the check passes.
+    if (h->gs_prefix == 1 && A.max_row_len <= IRR_ROW_LEN) return ITS_OK;
+    PhaseTimer pt("gs_prefix");
+    double *diag_dev = nullptr; int *flags = nullptr;
+    auto give_up = [&]() { dfree(diag_dev); dfree(flags); h->err.clear(); (void)hipGetLastError(); return ITS_OK; };
+    if (dalloc(h, &diag_dev, (size_t)n) || dalloc(h, &flags, 4)) return give_up();
+    if (hipMemsetAsync(flags, 0, 4 * sizeof(int), h->stream) != hipSuccess) return give_up();
+    hipLaunchKernelGGL(gs_prefix_check_kernel, dim3((n + ITS_BLOCK - 1) / ITS_BLOCK), dim3(ITS_BLOCK), 0, h->stream, n,
+                       A.row_ptr, A.col, A.val, L.row_ptr, L.col, L.val, U.row_ptr, U.col, U.val, diag_dev, flags);
+    int hflags[4] = {1, 0, 0, 0};
+    if (hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) return give_up();
+    pt.lap("rows of A == [L | diagonal | U] checked on the device");
+    if (hflags[0] & 1) return give_up();
+    const int64_t nnz_u = U.nnz, nnz_du = nnz_u + n;
+    std::vector<int> u_rp((size_t)n + 1), u_col((size_t)std::max<int64_t>(nnz_u, 1)), rp((size_t)n + 1), col((size_t)nnz_du);
+    std::vector<double> u_val((size_t)std::max<int64_t>(nnz_u, 1)), dg((size_t)n), val((size_t)nnz_du);
+    if (hipMemcpy(u_rp.data(), U.row_ptr, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(dg.data(), diag_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return give_up();
+    if (nnz_u && (hipMemcpy(u_col.data(), U.col, (size_t)nnz_u * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+                  hipMemcpy(u_val.data(), U.val, (size_t)nnz_u * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) return give_up();
+    dfree(diag_dev); dfree(flags);
+    its_host::assemble_diag_upper(n, u_rp.data(), u_col.data(), u_val.data(), dg.data(), rp.data(), col.data(), val.data());
+    pt.lap("D + U assembled on the host");
+    const bool setup_was = h->setup_done;
+    const int rc = its_upload_csr_local(h, ITS_MAT_DU, n, n, nnz_du, rp.data(), col.data(), val.data(), ITS_FMT_CSR_EXACT);
+    h->setup_done = setup_was;
+    if (rc != ITS_OK) { free_csr(h->mat[ITS_MAT_DU]); h->have[ITS_MAT_DU] = false; h->err.clear(); (void)hipGetLastError(); return ITS_OK; }
+    h->gs_prefix_ready = true;
+    pt.lap("plans and images of D + U");
+    return ITS_OK;
+}
+
+// forward solve (D+L) x = rhs, level by level (kernels.hpp:451-473); x may alias rhs.  acc_out (may alias rhs): every row's
+// chain sum is stored there (SpmvArgs::acc_out)
+static int sweep(its_handle *h, double *x, const double *rhs, int first_level = 0, double *acc_out = nullptr)
 {
     const CsrDev &L = h->mat[ITS_MAT_L];
     const bool dist = its_dist_active(h);
@@ -922,22 +1031,23 @@ static int sweep(its_handle *h, double *x, const double *rhs, int first_level = 
         const int cnt = h->level_ptr[l + 1] - h->level_ptr[l];
         if (h->level_empty_lo[l] >= 0 && h->sweep_stream) {
             const int lo = h->level_empty_lo[l];
-            launch_sweep_empty(x + lo, rhs + lo, h->D + lo, cnt, h->stream);
+            launch_sweep_empty(x + lo, rhs + lo, h->D + lo, cnt, h->stream, acc_out ? acc_out + lo : nullptr);
         } else if (h->level_ell[l].val && h->sweep_ell_levels && h->sweep_stream) {
-            launch_sweep_ell_view(L, h->level_ell[l], x, rhs, h->D, h->stream);
+            launch_sweep_ell_view(L, h->level_ell[l], x, rhs, h->D, h->stream, acc_out);
         } else if (h->level_desc_count[l] > 0 && h->sweep_stream) {
             SpmvArgs a; a.x = x; a.y = x; a.b = rhs; a.D = h->D;   // rows of a level never read each other's x
+            a.acc_out = acc_out;
             launch_spmv_exact_desc(L, h->sweep_desc + h->level_desc_first[l], h->level_desc_count[l], a, EPI_SWEEP, 0, h->stream);
         } else if (h->sw_w > 0 && h->sweep_ell && h->sweep_run && !dist && h->level_run_end[l] > l) {
             const int e = h->level_run_end[l];
-            launch_sweep_ell_run(L.n_rows, h->sw_w, l, e, h->level_ptr_dev, h->level_rows, h->sw_col, h->sw_val, h->sw_D, x, rhs, h->stream);
+            launch_sweep_ell_run(L.n_rows, h->sw_w, l, e, h->level_ptr_dev, h->level_rows, h->sw_col, h->sw_val, h->sw_D, x, rhs, h->stream, acc_out);
             l = e - 1;
             continue;
         } else if (h->sw_w > 0 && h->sweep_ell) {
             launch_sweep_ell_level(L.n_rows, h->sw_w, h->level_ptr[l], h->level_ptr[l + 1], h->level_rows, h->sw_col, h->sw_val,
-                                   h->sw_D, x, rhs, h->stream);
+                                   h->sw_D, x, rhs, h->stream, acc_out);
         } else {
-            launch_sweep_level(L, h->level_rows + h->level_ptr[l], cnt, h->level_nshort[l], x, rhs, h->D, h->stream);
+            launch_sweep_level(L, h->level_rows + h->level_ptr[l], cnt, h->level_nshort[l], x, rhs, h->D, h->stream, acc_out);
         }
         // row-partitioned: colour l is done on every rank, its boundary values go to the neighbours before any rank
         // starts colour l + 1 (stream order on both sides of the exchange)
@@ -985,8 +1095,10 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
             rc = build_levels(h, n);
         }
         if (rc) return rc;
+        pt.lap("sweep schedule");
+        if (solver_kind == ITS_GAUSS_SEIDEL && (rc = build_gs_prefix(h))) return rc;
     }
-    pt.lap("sweep schedule");
+    pt.lap("image of D + U (gs_prefix)");
     if (solver_kind == ITS_JACOBI && jacobi_mode == ITS_JACOBI_SHIPPED) {
         // The shipped sweep gathers from x_new, which is still all zeros on the first trip
         // (solver.hpp:225); x_old = x0 is overwritten by the swapped SpMV (jacobi.hpp:191)
@@ -1217,28 +1329,35 @@ static int trip_gs(its_handle *h, double *res_out)
     // the hub rows are on the wave-per-row launch, whose second chain is free: its_solve -gs, 200 000-row power-law matrix,
     // 0.63 -> 0.56 ms per trip)
     const CsrDev &Am = h->mat[ITS_MAT_A], &Um = h->mat[ITS_MAT_U];
+    // option "gs_prefix" (its_handle.h): the fused pass walks D + U only, its full chain starting from the sums the sweep left
+    // in tmp — the entries of L are read once per trip, by the sweep (power-law matrix, 10 M rows: the pass over A was 1.42 ms
+    // of the 2.47 ms trip)
+    const bool prefix = h->fused_residual && h->gs_prefix_ready && h->have[ITS_MAT_DU] && !its_dist_active(h);
+    const CsrDev &Fm = prefix ? h->mat[ITS_MAT_DU] : Am;
     const bool fused = h->fused_residual && Um.nnz == Am.n_upper && Um.n_upper == Um.nnz &&
                        Um.upper_col_sum == Am.upper_col_sum && Um.upper_val_xor == Am.upper_val_xor &&
-                       (Am.max_row_len <= IRR_ROW_LEN || spmv_panel_eligible(Am, u, EPI_GS_FUSED) || Am.irr_n_long > 0) && !its_dist_active(h);
+                       (Fm.max_row_len <= IRR_ROW_LEN || spmv_panel_eligible(Fm, u, EPI_GS_FUSED) || Fm.irr_n_long > 0) && !its_dist_active(h);
+    double *acc_io = (prefix && fused) ? h->tmp : nullptr;
     // first sweep level without entries in L (the first colour): its rows' next iterate is (b - U x) / D, which the fused
     // pass can store itself (ELL kernels) — into x_b, because other rows of that pass still read the current x
     const int lo0 = h->n_levels >= 2 ? h->level_empty_lo[0] : -1, hi0 = lo0 >= 0 ? lo0 + (h->level_ptr[1] - h->level_ptr[0]) : -1;
     SpmvArgs f; f.x = h->x; f.y = h->tmp; f.b = h->b; f.part_sum = h->part[0];
     const bool pre = fused && h->gs_first_level_fused && h->sweep_stream && lo0 >= 0 && (lo0 & 1) == 0 &&
-                     ((hi0 & 1) == 0 || hi0 == Am.n_rows) && spmv_ell_eligible(Am, f, EPI_GS_FUSED);
+                     ((hi0 & 1) == 0 || hi0 == Am.n_rows) && spmv_ell_eligible(Fm, f, EPI_GS_FUSED) && Fm.ell_kind != 3;
     if (!(fused && h->ahead)) {
         if ((rc = spmv_dispatch(h, h->mat[ITS_MAT_U], u, EPI_GS_RHS, ITS_FMT_CSR_EXACT))) return rc;   // gauss_seidel.hpp:144,177
         h->ahead_pre = false;
     }
     if (h->ahead_pre) {
-        if ((rc = sweep(h, h->x_b, h->tmp, 1))) return rc;                             // level 0 is already there
+        if ((rc = sweep(h, h->x_b, h->tmp, 1, acc_io))) return rc;                     // level 0 is already there
         std::swap(h->x, h->x_b);
         h->ahead_pre = false;
-    } else if ((rc = sweep(h, h->x, h->tmp))) return rc;                               // :227
+    } else if ((rc = sweep(h, h->x, h->tmp, 0, acc_io))) return rc;                    // :227
     if (fused) {
         f.x = h->x;
         if (pre) { f.y2 = h->x_b; f.y2_lo = lo0; f.y2_hi = hi0; f.D = h->D; }
-        if ((rc = spmv_dispatch(h, h->mat[ITS_MAT_A], f, EPI_GS_FUSED, ITS_FMT_CSR_EXACT))) return rc;
+        f.acc0 = acc_io;                                                               // (read and overwritten row by row: f.y is tmp too)
+        if ((rc = spmv_dispatch(h, Fm, f, EPI_GS_FUSED, ITS_FMT_CSR_EXACT))) return rc;
         h->ahead = true; h->ahead_pre = pre;
         return finish_scalar(h, h->part[0], res_out, FIN_SQRT);
     }

@@ -86,6 +86,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ell_kernel(
         if (EPI == EPI_SWEEP) { ELL_LD2(e0, a.b); ELL_LD2(e1, a.D); }
         const bool pre = EPI == EPI_GS_FUSED && a.y2 && row0 >= a.y2_lo && row0 < a.y2_hi;   // rows of the entry-free first level
         if (pre) ELL_LD2(e1, a.D);
+        double a0[2] = {0.0, 0.0};                               // where the full chain of the fused Gauss-Seidel pass starts (SpmvArgs::acc0)
+        if (EPI == EPI_GS_FUSED && a.acc0 && !pre) ELL_LD2(a0, a.acc0);
 #undef ELL_LD2
         int c[W][2];
 #pragma unroll
@@ -100,13 +102,14 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ell_kernel(
         for (int k = 0; k < W; ++k)
 #pragma unroll
             for (int r = 0; r < 2; ++r) xv[k][r] = a.x[c[k][r]];
-        double outv[2];
+        double outv[2], accs[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            double acc = 0.0, acc2 = 0.0, diag = 0.0;
+            double acc = 0.0, acc2 = a0[r], diag = 0.0;
 #pragma unroll
             for (int k = 0; k < W; ++k)
                 if (((iw[r] >> (4 * k)) & 15u) != 15u) chain_step<EPI>(c[k][r], row0 + r, v[k][r], xv[k][r], acc, acc2, diag);
+            accs[r] = acc;
             outv[r] = 0.0;
             if (r == 0 ? any : full) outv[r] = row_finish<EPI, DOT>(acc, acc2, diag, e0[r], e1[r], e2[r], lane_sum, lane_max);
         }
@@ -120,6 +123,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ell_kernel(
                 if (nt_store) __builtin_nontemporal_store(o2, reinterpret_cast<ell_v2d *>(a.y + row0));
                 else *reinterpret_cast<ell_v2d *>(a.y + row0) = o2;
             } else if (any) a.y[row0] = outv[0];
+        }
+        if (EPI == EPI_SWEEP && a.acc_out) {                    // the sweep's chain sums (SpmvArgs::acc_out)
+            if (full) { ell_v2d o2; o2.x = accs[0]; o2.y = accs[1]; *reinterpret_cast<ell_v2d *>(a.acc_out + row0) = o2; }
+            else if (any) a.acc_out[row0] = accs[0];
         }
     }
     if (DOT || EpiKind<EPI>::norm) {
@@ -198,8 +205,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ellw_kernel(
         if (EPI == EPI_SWEEP) { ELL_LD2(e0, a.b); ELL_LD2(e1, a.D); }
         const bool pre = EPI == EPI_GS_FUSED && a.y2 && row0 >= a.y2_lo && row0 < a.y2_hi;   // rows of the entry-free first level
         if (pre) ELL_LD2(e1, a.D);
+        double a0[2] = {0.0, 0.0};                               // where the full chain of the fused Gauss-Seidel pass starts (SpmvArgs::acc0)
+        if (EPI == EPI_GS_FUSED && a.acc0 && !pre) ELL_LD2(a0, a.acc0);
 #undef ELL_LD2
-        double acc[2] = {0.0, 0.0}, acc2[2] = {0.0, 0.0}, diag[2] = {0.0, 0.0};
+        double acc[2] = {0.0, 0.0}, acc2[2] = {a0[0], a0[1]}, diag[2] = {0.0, 0.0};
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) {
             double v[8][2], xv[8][2];
@@ -238,6 +247,10 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ellw_kernel(
                 if (nt_store) __builtin_nontemporal_store(o2, reinterpret_cast<ell_v2d *>(a.y + row0));
                 else *reinterpret_cast<ell_v2d *>(a.y + row0) = o2;
             } else if (any) a.y[row0] = outv[0];
+        }
+        if (EPI == EPI_SWEEP && a.acc_out) {                    // the sweep's chain sums (SpmvArgs::acc_out)
+            if (full) { ell_v2d o2; o2.x = acc[0]; o2.y = acc[1]; *reinterpret_cast<ell_v2d *>(a.acc_out + row0) = o2; }
+            else if (any) a.acc_out[row0] = acc[0];
         }
     }
     if (DOT || EpiKind<EPI>::norm) {
@@ -460,12 +473,13 @@ void launch_spmv_ell(const CsrDev &A, const SpmvArgs &a_in, int epi, hipStream_t
 // One contiguous level (a colour of a multicolour ordering) of crs_L swept on its own ELL image: rows [lo, lo + cnt) of L
 // as a matrix of their own whose vectors are the level's slices of x, rhs and D.  Column offsets are those of L, so the
 // gathers go through x + lo (columns relative to the view may be negative: everything a level reads lies before it).
-void launch_sweep_ell_view(const CsrDev &L, const SweepEll &v, double *x, const double *rhs, const double *D, hipStream_t s)
+void launch_sweep_ell_view(const CsrDev &L, const SweepEll &v, double *x, const double *rhs, const double *D, hipStream_t s, double *acc_out)
 {
     CsrDev V;
     V.n_rows = v.cnt; V.n_cols = L.n_cols; V.off_dict = L.off_dict; V.n_off = L.n_off;
     V.ell_val = v.val; V.ell_idx = v.idx; V.ell_w = v.w; V.ell_blocks = v.blocks; V.ell_kind = v.kind; V.ell_pb = v.pb;
     SpmvArgs a; a.x = x + v.lo; a.y = x + v.lo; a.b = rhs + v.lo; a.D = D + v.lo;
+    if (acc_out) a.acc_out = acc_out + v.lo;
     launch_spmv_ell(V, a, EPI_SWEEP, s);
 }
 

@@ -125,6 +125,8 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ellg_kernel(
         if (EPI == EPI_STORE && DOT) ELL_LD2(e0, a.dotv);
         if (EPI == EPI_RESIDUAL || EPI == EPI_JACOBI_REF || EPI == EPI_GS_RHS || EpiKind<EPI>::fused) ELL_LD2(e0, a.b);
         if (EPI == EPI_JACOBI_SHIPPED) { ELL_LD2(e0, a.D); ELL_LD2(e1, a.x); ELL_LD2(e2, a.b); }
+        double a0[2] = {0.0, 0.0};                               // where the full chain of the fused Gauss-Seidel pass starts (SpmvArgs::acc0)
+        if (EPI == EPI_GS_FUSED && a.acc0) ELL_LD2(a0, a.acc0);
 #undef ELL_LD2
         double xv[W][2];
 #pragma unroll
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_ellg_kernel(
         double outv[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            double acc = 0.0, acc2 = 0.0, diag = 0.0;
+            double acc = 0.0, acc2 = a0[r], diag = 0.0;
 #pragma unroll
             for (int k = 0; k < W; ++k)
                 if ((present[r] >> k) & 1u) chain_step<EPI>(c[k][r], row0 + r, v[k][r], xv[k][r], acc, acc2, diag);

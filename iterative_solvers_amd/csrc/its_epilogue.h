@@ -47,6 +47,20 @@ __device__ __forceinline__ void chain_step(int c, int row, double v, double x, d
     }
 }
 
+// where the full chain of a fused Gauss-Seidel pass starts (SpmvArgs::acc0) and where a sweep leaves its chain sum
+// (SpmvArgs::acc_out); both compile away for the other epilogues
+template <int EPI>
+__device__ __forceinline__ double chain2_start(const SpmvArgs &a, int row)
+{
+    if (EPI == EPI_GS_FUSED && a.acc0 && !(a.y2 && row >= a.y2_lo && row < a.y2_hi)) return a.acc0[row];
+    return 0.0;
+}
+template <int EPI>
+__device__ __forceinline__ void sweep_note(const SpmvArgs &a, int row, double acc)
+{
+    if (EPI == EPI_SWEEP && a.acc_out) a.acc_out[row] = acc;
+}
+
 template <int EPI, bool DOT>
 __device__ __forceinline__ void epi_operands(const SpmvArgs &a, int row, double &e0, double &e1, double &e2)
 {

@@ -26,8 +26,10 @@ struct its_handle {
     float prof_spmv_ms = 0.f;
     std::string err;
 
-    CsrDev mat[3];
-    bool have[3] = {false, false, false};
+    // A, crs_L, crs_U as uploaded, and ITS_MAT_DU: the rows of A from the diagonal on (D + U), built by its_solver_setup
+    // for Gauss-Seidel (option "gs_prefix", below) — never uploaded by a caller
+    CsrDev mat[4];
+    bool have[4] = {false, false, false, false};
     int fmt = ITS_FMT_CSR_EXACT;          // format used by the solver loops for A
     double mixed_threshold = 1.0;         // its_set_mixed_threshold: entries below it are stored in fp32 (ITS_FMT_MIXED)
 
@@ -87,6 +89,15 @@ struct its_handle {
     // "gs_first_level_fused", same bits).  ahead_pre = x_b holds it (only meaningful while `ahead`).
     bool ahead_pre = false;
     int gs_first_level_fused = 1;
+    // Gauss-Seidel, option "gs_prefix" (1): with ascending columns a row of A is [its entries of L | diagonal | its entries
+    // of U], so the in-order chain of the recorded residual b - A x_new begins with exactly the chain the sweep of that
+    // row has just run over L.  The sweep leaves its chain sums in tmp (in place of the right-hand side it has consumed),
+    // and the pass that records the residual and produces the next b - U x walks D + U only (mat[ITS_MAT_DU]), its full
+    // chain starting from those sums: the same operations in the same order — the same bits — with the entries of L
+    // read once per trip instead of twice.  gs_prefix_ready: its_solver_setup has verified on the device that crs_L,
+    // the diagonal and crs_U are A's rows entry for entry (bitwise, in order) and built the image.
+    int gs_prefix = 1;
+    bool gs_prefix_ready = false;
     bool setup_done = false, residual_done = false;
     double last_residual = 0.0;
     int watch_window_ms = 50;                    // option "watch_window_ms": how long its_iterate watches before it synchronizes
@@ -122,6 +133,7 @@ struct its_handle {
     DistPlan *dist = nullptr;
 };
 
+constexpr int ITS_MAT_DU = 3;             // its_handle::mat slot of the D + U image (internal)
 constexpr size_t PIN_RES = 8;             // index of the residual word inside its_handle::pinned
 constexpr size_t PIN_REGIONS = 16;        // first index of the restart-length-sized regions
 

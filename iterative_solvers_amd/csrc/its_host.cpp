@@ -225,6 +225,19 @@ void row_maxcol(int n_rows, const int *rp, const int *col, int limit, int *maxco
     }
 }
 
+void assemble_diag_upper(int n, const int *u_rp, const int *u_col, const double *u_val, const double *diag,
+                         int *rp, int *col, double *val)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i <= n; ++i) rp[i] = u_rp[i] + i;
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int i = 0; i < n; ++i) {
+        int64_t o = (int64_t)u_rp[i] + i;
+        col[o] = i; val[o] = diag[i]; ++o;
+        for (int k = u_rp[i]; k < u_rp[i + 1]; ++k, ++o) { col[o] = u_col[k]; val[o] = u_val[k]; }
+    }
+}
+
 void split_by_magnitude(int n_rows, const int *rp, const int *col, const double *val, double thr,
                         int *rp_d, int *col_d, double *val_d, int *rp_s, int *col_s, float *val_s)
 {

@@ -30,4 +30,9 @@ void row_maxcol(int n_rows, const int *rp, const int *col, int limit, int *maxco
 void split_by_magnitude(int n_rows, const int *rp, const int *col, const double *val, double thr,
                         int *rp_d, int *col_d, double *val_d, int *rp_s, int *col_s, float *val_s);
 
+// rows of A from the diagonal on (Gauss-Seidel, option "gs_prefix"): row i = (i, diag[i]) followed by row i of the strictly
+// upper part; rp sized n + 1, col / val sized nnz_U + n
+void assemble_diag_upper(int n, const int *u_rp, const int *u_col, const double *u_val, const double *diag,
+                         int *rp, int *col, double *val);
+
 }  // namespace its_host

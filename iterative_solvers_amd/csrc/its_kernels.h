@@ -139,6 +139,15 @@ struct SpmvArgs {
     // store (b - U x) / D, i.e. their next iterate, to y2 instead of b - U x to y (y2_lo even; y2_hi even or n_rows)
     double *y2 = nullptr;
     int y2_lo = 0, y2_hi = 0;
+    // Gauss-Seidel, "the sweep's chain is the residual's prefix" (its_api.hip trip_gs, option "gs_prefix"): with ascending
+    // columns a row of A is [entries of L | diagonal | entries of U], so the in-order chain of b - A x_new over the row
+    // starts with exactly the chain the sweep of that row has just run over L (same entries, same order, same x).
+    //   acc_out  EPI_SWEEP and the sweep kernels: the row's chain sum is stored here (may alias the sweep's rhs: every row
+    //            reads its rhs before it stores)
+    //   acc0     EPI_GS_FUSED over the image of D + U: the full chain of a row starts from acc0[row] instead of 0.0
+    //            (rows in [y2_lo, y2_hi) with y2 set — the first level, swept by the pass itself — start from 0.0)
+    const double *acc0 = nullptr;
+    double *acc_out = nullptr;
 };
 
 void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
@@ -147,7 +156,7 @@ void launch_spmv_exact(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStre
 // launch tunables of the exact SpMV ("spmv_grid", "spmv_map", "spmv_variant", "spmv_idx", "spmv_valdict", "spmv_irr",
 // "spmv_irr_len", "spmv_irr_grid", "spmv_bigplan"); 0 ok, -1 bad value, -2 unknown name
 int spmv_tune(const char *name, int value);
-void launch_sweep_empty(double *x, const double *rhs, const double *D, int64_t n, hipStream_t s);   // level without entries in L
+void launch_sweep_empty(double *x, const double *rhs, const double *D, int64_t n, hipStream_t s, double *acc_out = nullptr);   // level without entries in L
 void launch_spmv_exact_desc(const CsrDev &A, const int4 *desc, int n_desc, const SpmvArgs &a, int epilogue,
                             int accumulate, hipStream_t s);
 // true when this launch would walk CsrDev::blk_desc_big (callers that pass descriptor lists of their own must
@@ -160,7 +169,7 @@ bool spmv_ell_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);
 // ELL image of one contiguous sweep level of crs_L (its_api.hip build_levels, its_ell.hip launch_sweep_ell_view)
 struct SweepEll { double *val = nullptr; uint32_t *idx = nullptr; int w = 0, blocks = 0, kind = 0, lo = 0, cnt = 0, pb = 0; };
 int ell_choose_period(const int *dict, int n_off);    // row blocks per period of the ELL work map, 0 = none (its_ell.hip)
-void launch_sweep_ell_view(const CsrDev &L, const SweepEll &v, double *x, const double *rhs, const double *D, hipStream_t s);
+void launch_sweep_ell_view(const CsrDev &L, const SweepEll &v, double *x, const double *rhs, const double *D, hipStream_t s, double *acc_out = nullptr);
 // the wave-per-row launch for a list of long rows (its_panel.hip); partial sums are ADDED to the ones a launch before it wrote
 void launch_spmv_long(const CsrDev &A, const int *rows, int n_long, const SpmvArgs &a, int epilogue, hipStream_t s);
 bool spmv_panel_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);     // its_panel.hip
@@ -248,7 +257,7 @@ constexpr int SWEEP_HUB = 512;            // a row of L this long is started fir
 constexpr int SWEEP_SHORT = 16;            // rows of L up to this length take one lane, longer ones one wave
 // rows[0, n_short) must be the short rows of the level, rows[n_short, n_level_rows) the long ones
 void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int n_short, double *x,
-                        const double *rhs, const double *D, hipStream_t s);
+                        const double *rhs, const double *D, hipStream_t s, double *acc_out = nullptr);
 // level-ordered copy of L (rows of at most SWEEP_ELL_W entries): slot-major (col, val) + diagonal per list position
 constexpr int SWEEP_ELL_W = 16;           // (rows of L of a 27-point stencil have up to 13 entries)
 void launch_sweep_ell_build(int n, int W, const int *rows, const CsrDev &L, const double *D, int *sw_col, double *sw_val,
@@ -256,8 +265,8 @@ void launch_sweep_ell_build(int n, int W, const int *rows, const CsrDev &L, cons
 // a run of consecutive levels of at most sweep_run_rows(W) list positions each, in one launch of one workgroup
 int sweep_run_rows(int W);
 void launch_sweep_ell_run(int n, int W, int l0, int l1, const int *level_ptr_dev, const int *rows, const int *sw_col,
-                          const double *sw_val, const double *sw_D, double *x, const double *rhs, hipStream_t s);
+                          const double *sw_val, const double *sw_D, double *x, const double *rhs, hipStream_t s, double *acc_out = nullptr);
 void launch_sweep_ell_level(int n, int W, int p0, int p1, const int *rows, const int *sw_col, const double *sw_val,
-                            const double *sw_D, double *x, const double *rhs, hipStream_t s);
+                            const double *sw_D, double *x, const double *rhs, hipStream_t s, double *acc_out = nullptr);
 
 }  // namespace its

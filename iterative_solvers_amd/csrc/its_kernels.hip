@@ -161,7 +161,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
         int4 dnn = blk_desc[min(rb + 2 * rstep, rb_last)]; dnn.y &= 0xffff;
         const int rs = d.x, nr = d.y;
         const int row = rs + t;
-        double acc = 0.0, acc2 = 0.0, diag = 0.0;
+        double acc = 0.0, acc2 = t < nr ? chain2_start<EPI>(a, row) : 0.0, diag = 0.0;
         // (a matrix with a dictionary has no row longer than its 256 offsets: no long-row path under IDX)
         const bool lng = !IDX && d.w - d.z > NNZ_CAP;
         if (!lng) {
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream2_kernel(
             epi_operands<EPI, DOT>(a, row, e0, e1, e2);
             const double outv = row_finish<EPI, DOT>(acc, acc2, diag, e0, e1, e2, lane_sum, lane_max);
             if (a.y) st_d1<NT>(a.y + row, outv);             // y == nullptr: only the norm is wanted
+            sweep_note<EPI>(a, row, acc);
         }
         cur ^= 1;
         d = dn; dn = dnn;
@@ -534,12 +535,13 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_stream5_kernel(
     // the in-order chain of the row block whose gathers sit in Gs, its epilogue, result parked
 #define S5_FINISH(Gs)                                                                     \
     do {                                                                                  \
-        double acc = 0.0, acc2 = 0.0, diag = 0.0;                                         \
+        double acc = 0.0, acc2 = t < Gs.nr ? chain2_start<EPI>(a, Gs.row) : 0.0, diag = 0.0; \
         _Pragma("unroll") for (int u = 0; u < 8; ++u)                                     \
             if (Gs.j + u < Gs.j1) chain_step<EPI>(Gs.c[u], Gs.row, Gs.v[u], Gs.x[u], acc, acc2, diag); \
         if (t < Gs.nr) {                                                                  \
             const double outv = row_finish<EPI, DOT>(acc, acc2, diag, Gs.e0, Gs.e1, Gs.e2, lane_sum, lane_max); \
             if (a.y) { pend_val = outv; pend_row = Gs.row; }                              \
+            sweep_note<EPI>(a, Gs.row, acc);                                              \
         }                                                                                 \
     } while (0)
     // one trip: R = register set of row block it+1, GN = its gather set, GO = gather set of row block it
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(ITS_BLOCK, 5) void spmv_irr_kernel(
         const int rbn = rb + rstep;
         int4 dn = make_int4(0, 0, 0, 0);
         if (rbn < rb1) dn = blk_desc[rbn];
-        double acc = 0.0, acc2 = 0.0, diag = 0.0;
+        double acc = 0.0, acc2 = t < nr ? chain2_start<EPI>(a, row) : 0.0, diag = 0.0;
         int my_rp = 0;
         if (t < nr) my_rp = rp[d.x + t];
         for (int c0 = d.z; ; c0 += SPMV_NNZ_MAX) {
@@ -741,6 +743,7 @@ __global__ __launch_bounds__(ITS_BLOCK, 5) void spmv_irr_kernel(
             epi_operands<EPI, DOT>(a, row, e0, e1, e2);
             const double outv = row_finish<EPI, DOT>(acc, acc2, diag, e0, e1, e2, lane_sum, lane_max);
             if (a.y) a.y[row] = outv;                        // y == nullptr: only the norm is wanted
+            sweep_note<EPI>(a, row, acc);
         }
     }
 #undef IRR_ISSUE
@@ -1363,14 +1366,17 @@ void launch_axpby(double *out, const double *a, const double *b, int64_t n, doub
 { hipLaunchKernelGGL(axpby_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, out, a, b, n, sc); }
 // a sweep level whose rows have no entries in L: x_i = (rhs_i - 0.0) / D_i, the value the chain kernels give for an empty
 // row (rhs - (+0.0) == rhs bit for bit)
-__global__ __launch_bounds__(ITS_BLOCK) void sweep_empty_kernel(double *x, const double *rhs, const double *__restrict__ D, int64_t n)
+__global__ __launch_bounds__(ITS_BLOCK) void sweep_empty_kernel(double *x, const double *rhs, const double *__restrict__ D, int64_t n, double *acc_out)
 {
     const int64_t tid = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * ITS_BLOCK;
-    for (int64_t i = tid; i < n; i += nth) x[i] = (rhs[i] - 0.0) / D[i];
+    for (int64_t i = tid; i < n; i += nth) {
+        x[i] = (rhs[i] - 0.0) / D[i];
+        if (acc_out) acc_out[i] = 0.0;               // the chain of an empty row (SpmvArgs::acc_out)
+    }
 }
-void launch_sweep_empty(double *x, const double *rhs, const double *D, int64_t n, hipStream_t s)
-{ hipLaunchKernelGGL(sweep_empty_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, x, rhs, D, n); }
+void launch_sweep_empty(double *x, const double *rhs, const double *D, int64_t n, hipStream_t s, double *acc_out)
+{ hipLaunchKernelGGL(sweep_empty_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, x, rhs, D, n, acc_out); }
 
 void launch_scale(double *out, const double *v, double sc, int64_t n, hipStream_t s)
 { hipLaunchKernelGGL(scale_kernel, vgrid(n), dim3(ITS_BLOCK), 0, s, out, v, sc, n); }
@@ -1576,7 +1582,7 @@ constexpr int SWEEP_MERGE_ROWS = 1 << 18;           // levels up to this size wi
 
 __device__ __forceinline__ void sweep_short_rows(
     int bid, int nb, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
-    const int *__restrict__ rows, int n_short, double *x, const double *__restrict__ rhs, const double *__restrict__ D)
+    const int *__restrict__ rows, int n_short, double *x, const double *rhs, const double *__restrict__ D, double *acc_out)
 {
     {
         const int64_t nth = (int64_t)nb * ITS_BLOCK;
@@ -1598,19 +1604,20 @@ __device__ __forceinline__ void sweep_short_rows(
                 for (int u = 0; u < 8; ++u) if (j + u < j1) s = fma(v[u], xv[u], s);
             }
             x[row] = (rhs[row] - s) / D[row];
+            if (acc_out) acc_out[row] = s;
         }
     }
 }
 
 __global__ __launch_bounds__(ITS_BLOCK) void sweep_short_kernel(
     const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
-    const int *__restrict__ rows, int n_short, double *x, const double *__restrict__ rhs, const double *__restrict__ D)
-{ sweep_short_rows(blockIdx.x, gridDim.x, rp, col, val, rows, n_short, x, rhs, D); }
+    const int *__restrict__ rows, int n_short, double *x, const double *rhs, const double *__restrict__ D, double *acc_out)
+{ sweep_short_rows(blockIdx.x, gridDim.x, rp, col, val, rows, n_short, x, rhs, D, acc_out); }
 
 __device__ __forceinline__ void sweep_long_rows(
     int bid, int nb, double2 (*s_vx)[SWEEP_CHUNK + 8], const int *__restrict__ rp, const int *__restrict__ col,
     const double *__restrict__ val, const int *__restrict__ rows, int n_level_rows, int n_short, double *x,
-    const double *__restrict__ rhs, const double *__restrict__ D)
+    const double *rhs, const double *__restrict__ D, double *acc_out)
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     // Long rows.  The chain is serial by definition (one fused multiply-add per entry, in CRS order), so the
@@ -1659,7 +1666,7 @@ __device__ __forceinline__ void sweep_long_rows(
             }
 #undef SWEEP_LW_LOAD
 #undef SWEEP_LW_GATHER
-            if (l == 0) x[row] = (rhs[row] - acc) / D[row];
+            if (l == 0) { x[row] = (rhs[row] - acc) / D[row]; if (acc_out) acc_out[row] = acc; }
             continue;
         }
         int cn[SWEEP_LPL];                    // columns of the chunk after next
@@ -1709,7 +1716,7 @@ __device__ __forceinline__ void sweep_long_rows(
         }
 #undef SWEEP_LOAD_CV
 #undef SWEEP_GATHER
-        if (l == 0) x[row] = (rhs[row] - acc) / D[row];
+        if (l == 0) { x[row] = (rhs[row] - acc) / D[row]; if (acc_out) acc_out[row] = acc; }
     }
 }
 
@@ -1718,10 +1725,10 @@ __device__ __forceinline__ void sweep_long_rows(
 __global__ __launch_bounds__(ITS_BLOCK) void sweep_long_kernel(
     const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
     const int *__restrict__ rows, int n_level_rows, int n_short, double *x,
-    const double *__restrict__ rhs, const double *__restrict__ D)
+    const double *rhs, const double *__restrict__ D, double *acc_out)
 {
     __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][SWEEP_CHUNK + 8];   // + 8: the walk's last batch may read past the chunk
-    sweep_long_rows(blockIdx.x, gridDim.x, s_vx, rp, col, val, rows, n_level_rows, n_short, x, rhs, D);
+    sweep_long_rows(blockIdx.x, gridDim.x, s_vx, rp, col, val, rows, n_level_rows, n_short, x, rhs, D, acc_out);
 }
 
 // A level that has both kinds of rows and is small (a natural-order sweep of an irregular matrix: two dozen levels of a
@@ -1730,11 +1737,11 @@ __global__ __launch_bounds__(ITS_BLOCK) void sweep_long_kernel(
 __global__ __launch_bounds__(ITS_BLOCK) void sweep_level_kernel(
     const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
     const int *__restrict__ rows, int n_level_rows, int n_short, int gl, double *x,
-    const double *__restrict__ rhs, const double *__restrict__ D)
+    const double *rhs, const double *__restrict__ D, double *acc_out)
 {
     __shared__ double2 s_vx[ITS_BLOCK / ITS_WAVE][SWEEP_CHUNK + 8];
-    if ((int)blockIdx.x < gl) sweep_long_rows(blockIdx.x, gl, s_vx, rp, col, val, rows, n_level_rows, n_short, x, rhs, D);
-    else sweep_short_rows(blockIdx.x - gl, gridDim.x - gl, rp, col, val, rows, n_short, x, rhs, D);
+    if ((int)blockIdx.x < gl) sweep_long_rows(blockIdx.x, gl, s_vx, rp, col, val, rows, n_level_rows, n_short, x, rhs, D, acc_out);
+    else sweep_short_rows(blockIdx.x - gl, gridDim.x - gl, rp, col, val, rows, n_short, x, rhs, D, acc_out);
 }
 
 // --------------------------------------------------------------------------------------
@@ -1764,7 +1771,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void sweep_ell_build_kernel(
 template <int W>
 __global__ __launch_bounds__(ITS_BLOCK) void sweep_ell_kernel(
     int n, int p0, int p1, const int *__restrict__ rows, const int *__restrict__ sw_col, const double *__restrict__ sw_val,
-    const double *__restrict__ sw_D, double *x, const double *__restrict__ rhs)
+    const double *__restrict__ sw_D, double *x, const double *rhs, double *acc_out)
 {
     const int p = p0 + blockIdx.x * ITS_BLOCK + threadIdx.x;
     if (p >= p1) return;
@@ -1780,6 +1787,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void sweep_ell_kernel(
 #pragma unroll
     for (int s = 0; s < W; ++s) if (c[s] >= 0) acc = fma(v[s], xv[s], acc);
     x[row] = (r - acc) / d;
+    if (acc_out) acc_out[row] = acc;
 }
 
 void launch_sweep_ell_build(int n, int W, const int *rows, const CsrDev &L, const double *D, int *sw_col, double *sw_val,
@@ -1791,11 +1799,11 @@ void launch_sweep_ell_build(int n, int W, const int *rows, const CsrDev &L, cons
 }
 
 void launch_sweep_ell_level(int n, int W, int p0, int p1, const int *rows, const int *sw_col, const double *sw_val,
-                            const double *sw_D, double *x, const double *rhs, hipStream_t s)
+                            const double *sw_D, double *x, const double *rhs, hipStream_t s, double *acc_out)
 {
     if (p1 <= p0) return;
     dim3 g((p1 - p0 + ITS_BLOCK - 1) / ITS_BLOCK), b(ITS_BLOCK);
-#define ITS_LAUNCHSW(WW) hipLaunchKernelGGL((sweep_ell_kernel<WW>), g, b, 0, s, n, p0, p1, rows, sw_col, sw_val, sw_D, x, rhs)
+#define ITS_LAUNCHSW(WW) hipLaunchKernelGGL((sweep_ell_kernel<WW>), g, b, 0, s, n, p0, p1, rows, sw_col, sw_val, sw_D, x, rhs, acc_out)
     switch (W) {
     case 1: ITS_LAUNCHSW(1); break;
     case 2: ITS_LAUNCHSW(2); break;
@@ -1829,7 +1837,7 @@ void launch_sweep_ell_level(int n, int W, int p0, int p1, const int *rows, const
 template <int W, int NT>
 __global__ __launch_bounds__(NT) void sweep_ell_run_kernel(
     int n, int l0, int l1, const int *__restrict__ lptr, const int *__restrict__ rows, const int *__restrict__ sw_col,
-    const double *__restrict__ sw_val, const double *__restrict__ sw_D, double *x, const double *rhs)
+    const double *__restrict__ sw_val, const double *__restrict__ sw_D, double *x, const double *rhs, double *acc_out)
 {
     const int t = threadIdx.x;
     int row = 0, c[W]; double v[W], d = 1.0, r = 0.0; bool have = false;
@@ -1871,6 +1879,7 @@ __global__ __launch_bounds__(NT) void sweep_ell_run_kernel(
 #pragma unroll
             for (int s = 0; s < W; ++s) if (c[s] >= 0) acc = fma(v[s], xv[s], acc);
             x[row] = (r - acc) / d;
+            if (acc_out) acc_out[row] = acc;     // (may alias rhs: rhs[row] was read a level ago, by this lane)
         }
         __syncthreads();
         have = haven; row = rown; d = dn; r = rn;
@@ -1880,11 +1889,11 @@ __global__ __launch_bounds__(NT) void sweep_ell_run_kernel(
 }
 
 void launch_sweep_ell_run(int n, int W, int l0, int l1, const int *level_ptr_dev, const int *rows, const int *sw_col,
-                          const double *sw_val, const double *sw_D, double *x, const double *rhs, hipStream_t s)
+                          const double *sw_val, const double *sw_D, double *x, const double *rhs, hipStream_t s, double *acc_out)
 {
     if (l1 <= l0) return;
     dim3 g(1);
-#define ITS_LAUNCHSR(WW, NT) hipLaunchKernelGGL((sweep_ell_run_kernel<WW, NT>), g, dim3(NT), 0, s, n, l0, l1, level_ptr_dev, rows, sw_col, sw_val, sw_D, x, rhs)
+#define ITS_LAUNCHSR(WW, NT) hipLaunchKernelGGL((sweep_ell_run_kernel<WW, NT>), g, dim3(NT), 0, s, n, l0, l1, level_ptr_dev, rows, sw_col, sw_val, sw_D, x, rhs, acc_out)
     switch (W) {
     case 1: ITS_LAUNCHSR(1, 1024); break;
     case 2: ITS_LAUNCHSR(2, 1024); break;
@@ -1908,7 +1917,7 @@ void launch_sweep_ell_run(int n, int W, int l0, int l1, const int *level_ptr_dev
 int sweep_run_rows(int W) { return W <= 8 ? 1024 : 512; }
 
 void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int n_short, double *x,
-                        const double *rhs, const double *D, hipStream_t s)
+                        const double *rhs, const double *D, hipStream_t s, double *acc_out)
 {
     if (n_level_rows <= 0) return;
     if (!rows) n_short = n_level_rows;                       // identity order has no long-row list
@@ -1920,14 +1929,14 @@ void launch_sweep_level(const CsrDev &L, const int *rows, int n_level_rows, int 
     // rows of a level are independent, so the order of the two launches does not matter
     if (gs > 0 && gl > 0 && n_level_rows <= SWEEP_MERGE_ROWS) {
         hipLaunchKernelGGL(sweep_level_kernel, dim3(gl + gs), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val, rows, n_level_rows,
-                           n_short, gl, x, rhs, D);
+                           n_short, gl, x, rhs, D, acc_out);
         return;
     }
     if (gs > 0)
-        hipLaunchKernelGGL(sweep_short_kernel, dim3(gs), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val, rows, n_short, x, rhs, D);
+        hipLaunchKernelGGL(sweep_short_kernel, dim3(gs), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val, rows, n_short, x, rhs, D, acc_out);
     if (gl > 0)
         hipLaunchKernelGGL(sweep_long_kernel, dim3(gl), dim3(ITS_BLOCK), 0, s, L.row_ptr, L.col, L.val, rows, n_level_rows,
-                           n_short, x, rhs, D);
+                           n_short, x, rhs, D, acc_out);
 }
 
 }  // namespace its

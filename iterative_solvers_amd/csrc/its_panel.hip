@@ -237,9 +237,11 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_panel_kernel(
     const int G = gridDim.x;
     double lane_sum = 0.0, lane_max = 0.0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += G) {
-        for (int i = t; i < NACC * PAN_TR; i += ITS_BLOCK) s_acc[i] = 0.0;
         const int d0 = tile_ptr[tile], d1 = tile_ptr[tile + 1];
         const int trow0 = tile_row[tile], trows = tile_row[tile + 1] - trow0;
+        for (int i = t; i < PAN_TR; i += ITS_BLOCK) s_acc[i] = 0.0;
+        // the full chain of the fused Gauss-Seidel pass over D + U starts from the sweep's chain over L (SpmvArgs::acc0)
+        if (NACC == 2) for (int i = t; i < PAN_TR; i += ITS_BLOCK) s_acc[PAN_TR + i] = i < trows ? chain2_start<EPI>(a, trow0 + i) : 0.0;
         // software pipeline over the tile's chunks: entries two chunks ahead, gathers one chunk ahead of the chains
         uint32_t k0 = 0, k1 = 0; double v0 = 0.0, v1 = 0.0, x0 = 0.0;
         int m0 = 0, m1 = 0, p0 = 0, p1 = 0;
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_long_kernel(
 #if ITS_LONG_LANEWALK
         if (!COLS && !FUSED && rj1 - rj0 >= LW_MIN_LEN) continue;      // (walked above)
 #endif
-        double acc1 = 0.0;                               // this lane's chain (lane 0: the epilogue's own, lane 1: the full one of the fused forms)
+        double acc1 = (FUSED && l == 1) ? chain2_start<EPI>(a, row) : 0.0;   // this lane's chain (lane 0: the epilogue's own, lane 1: the full one of the fused forms)
         double dg_l = 0.0; int dg_at = -1;               // Jacobi forms: the diagonal entry this lane staged last, and where
         int cn[LONG_LPL], cc[LONG_LPL]; double vn[LONG_LPL], vv[LONG_LPL], xg[LONG_LPL];
         const double2 *strip = (FUSED && l == 0) ? s_m[FUSED ? w : 0] : s_vx[w];
