@@ -58,7 +58,7 @@ def kernel_sources_hash():
     import hashlib
     hsh = hashlib.sha256()
     # the files that hold device code (host-side API changes do not invalidate a counter profile)
-    names = ("its_kernels.hip", "its_ell.hip", "its_ellg.hip", "its_panel.hip", "its_mgs.hip", "its_epilogue.h", "its_device.h", "its_kernels.h")
+    names = ("its_kernels.hip", "its_ell.hip", "its_ellg.hip", "its_ellm.hip", "its_panel.hip", "its_mgs.hip", "its_epilogue.h", "its_device.h", "its_kernels.h", "its_ap.h")
     for f in sorted(os.path.join(ROOT, "iterative_solvers_amd", "csrc", nm) for nm in names):
         hsh.update(os.path.basename(f).encode()); hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]
@@ -75,6 +75,17 @@ def pmc_traffic(kernel_substr):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.txt")))
     if not files:
         return None, "no profiles/*pmc_summary.txt"
+    # the newest summary taken with THESE kernel sources that lists the kernel (several summaries share a round's prefix:
+    # the headline run's, the configs', the 512-slab rehearsal's), else the newest by name for the note
+    want = kernel_sources_hash()
+    def stamp_of(f):
+        for line in open(f):
+            if line.startswith("# kernel_sources_sha256="):
+                return line.split("=", 1)[1].strip()
+        return None
+    match = [f for f in files if stamp_of(f) == want and any(kernel_substr in l and l.startswith("FETCH_SIZE") for l in open(f))]
+    if match:
+        files = match
     fetch = write = None
     stamp = None
     for line in open(files[-1]):
@@ -407,6 +418,37 @@ def generic_spmv_entries(h, capi, rp, col, val, n, nnz, xd, yd, reps):
     return out
 
 
+def mixed_precision_entries(capi, S, device, rp, col, val, n, nnz, steps, reps):
+    """SURVEY.md §8f.3 (the reference's USE_AP idea, config.mk:56-63), opt-in, never `value`: the SAME C2 system with its
+    entries stored by magnitude — AP_THRESHOLD_1 = 2: the diagonal (6) in fp64, the off-diagonals (-1) in fp32 (ap[dp_sp])
+    or fp16 (ap[dp_hp]) — on the tiered sliced-ELL image (csrc/its_ellm.hip).  x, y and the accumulation stay fp64 and the
+    chain order is the reference's, so for this matrix (-1 is exact in every type) the iterates are those of the fp64 run."""
+    out = {}
+    for tag, mode in (("ap[dp_sp]", capi.AP_DP_SP), ("ap[dp_hp]", capi.AP_DP_HP)):
+        sol = S.Solver("conjugate-gradient", device=device, spmv_format=capi.FMT_MIXED)
+        h = sol.handle
+        try:
+            h.set_mixed_mode(mode, 2.0, 0.0)
+            args = S.Args("conjugate-gradient", S.LoopParams(max_iters=10**9, tol=0.0))
+            S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+            tiers = h.mixed_tiers()
+            xd = h.to_dev(np.ones(n)); yd = h.dev_alloc(8 * n)
+            h.spmv_timed(xd, yd, capi.FMT_MIXED, reps=3, with_dot=True)
+            ms = h.spmv_timed(xd, yd, capi.FMT_MIXED, reps=reps, with_dot=True)
+            h.iterate_n(0, 20)
+            res = h.iterate_n(20, steps)
+            streamed = tiers["value_bytes"] + 4 * n + 16 * n            # values + one index word per row + x once + y once
+            out[tag] = {"threshold_1": 2.0, "form": "tiered sliced ELL" if tiers["ell_form"] else "CRS split",
+                        "entries_fp64_fp32_fp16": tiers["nnz"], "matrix_value_bytes": tiers["value_bytes"],
+                        "spmv_ms": ms, "streamed_bytes": streamed, "GBps_streamed": streamed / ms / 1e6,
+                        "GBps_csr_equivalent": spmv_bytes(n, nnz) / ms / 1e6,
+                        "cg_ms_per_step": h.last_region_ms() / steps, "last_residual": float(res[-1])}
+            h.dev_free(xd); h.dev_free(yd)
+        finally:
+            h.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -590,6 +632,11 @@ def main():
             opt_in = {"spmv_valdict": {"spmv_ms": ms_vd, "cg_ms_per_step": h.last_region_ms() / a.steps,
                                        "streamed_bytes": spmv_bytes(n, nnz) - 10 * nnz}}
             h.set_option("spmv_valdict", 0)
+            if c2_single and not a.no_generic:
+                try:
+                    opt_in["mixed_precision"] = mixed_precision_entries(capi, S, local_rank % n_dev, rp, col, val, n, nnz, a.steps, a.spmv_reps)
+                except Exception as e:                             # an extra: never fails the bench line
+                    opt_in["mixed_precision"] = {"error": repr(e)[:200]}
         cpu = None
         if not a.no_cpu and world == 1 and not force_dist:
             cpu = cpu_baseline(rp, col, val, n)

@@ -71,6 +71,19 @@ int its_set_mixed_threshold(its_handle *h, double threshold);
 /* entries kept in fp64 / stored in fp32 by the last ITS_FMT_MIXED upload of this matrix (dp_percent / sp_percent of
  * main.cpp:186-190) */
 int its_mixed_info(its_handle *h, int which, int64_t *nnz_fp64, int64_t *nnz_fp32);
+/* The reference's AP_VALUE_TYPE (config.mk:57: "ap[dp_sp]", "ap[dp_hp]", "ap[sp_hp]", "ap[dp_sp_hp]") with AP_THRESHOLD_1 and
+ * AP_THRESHOLD_2 (config.mk:59-62), for the ITS_FMT_MIXED uploads that follow: an entry with |a_ij| >= threshold_1 is stored
+ * in the mode's first type, a smaller one in the second; in the three-type mode entries below threshold_2 in fp16.  An entry
+ * its type cannot hold (|a_ij| > 65504 for fp16) stays one type up.  fp16 entries are the fp32-rounded value rounded to
+ * binary16.  x, y and the accumulation stay fp64.  (partition_precisions itself, main.cpp:171-184, lives in the USpMV
+ * library, which is not part of the reference tree: the split follows its parameters — parity unpinned.)
+ * Matrices with rows of <= 8 entries and <= 15 distinct col - row are multiplied from a tiered sliced-ELL image in CRS
+ * order: BIT-identical to spmv_crs_cpu (kernels.hpp:380-409) applied to the matrix of the stored values. */
+enum { ITS_AP_DP_SP = 0, ITS_AP_DP_HP = 1, ITS_AP_SP_HP = 2, ITS_AP_DP_SP_HP = 3 };
+int its_set_mixed_mode(its_handle *h, int ap_value_type, double threshold_1, double threshold_2);
+/* entries per storage type of the last ITS_FMT_MIXED upload (nnz_by_tier[3]: fp64, fp32, fp16 — dp_percent, sp_percent,
+ * hp_percent of main.cpp:186-190), the bytes of matrix VALUES a product streams, and whether it walks the tiered ELL image */
+int its_mixed_tiers(its_handle *h, int which, int64_t *nnz_by_tier, int64_t *value_bytes, int *ell_form);
 /* after extract_diag + generate_vector + scale_vector (main.cpp:268-276): D, b, x_old. */
 int its_upload_vectors(its_handle *h, const double *D, const double *b, const double *x0, int n);
 /* Solver::init_residual (solver.hpp:838-855) + both norms that

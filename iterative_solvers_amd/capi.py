@@ -19,6 +19,7 @@ JACOBI, GAUSS_SEIDEL, CG, GMRES = 0, 1, 2, 3
 JACOBI_SHIPPED, JACOBI_REF = 0, 1
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_GS = 0, 1, 2
 FMT_CSR_EXACT, FMT_CSR_VECTOR, FMT_SELL, FMT_MIXED = 0, 1, 2, 3
+AP_DP_SP, AP_DP_HP, AP_SP_HP, AP_DP_SP_HP = 0, 1, 2, 3          # the reference's AP_VALUE_TYPE (config.mk:57)
 MAT_A, MAT_L, MAT_U = 0, 1, 2
 GS_LEVEL, GS_MULTICOLOR = 0, 1
 
@@ -36,6 +37,8 @@ SIGNATURES = {
     "its_upload_crs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "its_set_mixed_threshold": (C.c_int, [C.c_void_p, C.c_double]),
     "its_mixed_info": (C.c_int, [C.c_void_p, C.c_int, _c_i64_p, _c_i64_p]),
+    "its_set_mixed_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double]),
+    "its_mixed_tiers": (C.c_int, [C.c_void_p, C.c_int, _c_i64_p, _c_i64_p, _c_int_p]),
     "its_upload_vectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "its_init_residual": (C.c_int, [C.c_void_p, _c_dbl_p, _c_dbl_p]),
     "its_solver_setup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -198,6 +201,15 @@ class Handle:
 
     def set_mixed_threshold(self, thr: float):
         self.check(self.L.its_set_mixed_threshold(self.h, float(thr)), "its_set_mixed_threshold")
+
+    def set_mixed_mode(self, ap_value_type: int, threshold_1: float, threshold_2: float = 0.0):
+        self.check(self.L.its_set_mixed_mode(self.h, int(ap_value_type), float(threshold_1), float(threshold_2)), "its_set_mixed_mode")
+
+    def mixed_tiers(self, which=MAT_A):
+        """entries stored as fp64 / fp32 / fp16, bytes of matrix values a product streams, tiered-ELL form or CRS split"""
+        nz = (C.c_int64 * 3)(); vb = C.c_int64(); ef = C.c_int()
+        self.check(self.L.its_mixed_tiers(self.h, which, nz, C.byref(vb), C.byref(ef)), "its_mixed_tiers")
+        return {"nnz": list(nz), "value_bytes": vb.value, "ell_form": bool(ef.value)}
 
     def mixed_info(self, which=MAT_A):
         a, b = C.c_int64(), C.c_int64()

@@ -50,6 +50,7 @@ static void free_csr(CsrDev &A)
     dfree(A.ell_val); dfree(A.ell_idx); dfree(A.ellg_desc); dfree(A.ellg_base);
     dfree(A.pan_key); dfree(A.pan_val); dfree(A.pan_desc); dfree(A.pan_tile_ptr); dfree(A.pan_tile_row); dfree(A.pan_long); dfree(A.pan_diag); dfree(A.pan_long_rows);
     dfree(A.mix_rp_d); dfree(A.mix_col_d); dfree(A.mix_val_d); dfree(A.mix_rp_s); dfree(A.mix_col_s); dfree(A.mix_val_s);
+    dfree(A.mix_rp_h); dfree(A.mix_col_h); dfree(A.mix_val_h); dfree(A.ellm_img); dfree(A.ellm_tier); dfree(A.ellm_off);
     A = CsrDev();
 }
 
@@ -396,15 +397,21 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     pt.lap("stream plans + statistics");
     if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; pt.lap("SELL image"); }
     if (format == ITS_FMT_MIXED) {
-        std::vector<int> rpd((size_t)n_rows + 1), rps((size_t)n_rows + 1), cd((size_t)std::max<int64_t>(nnz, 1)), cs((size_t)std::max<int64_t>(nnz, 1));
-        std::vector<double> vd((size_t)std::max<int64_t>(nnz, 1));
-        std::vector<float> vs((size_t)std::max<int64_t>(nnz, 1));
-        its_host::split_by_magnitude(n_rows, row_ptr, col, val, h->mixed_threshold, rpd.data(), cd.data(), vd.data(), rps.data(), cs.data(), vs.data());
-        A.mix_nnz_d = rpd[n_rows]; A.mix_nnz_s = rps[n_rows];
-        if (dalloc(h, &A.mix_rp_d, (size_t)n_rows + 1) || dalloc(h, &A.mix_rp_s, (size_t)n_rows + 1) || dalloc(h, &A.mix_col_d, (size_t)A.mix_nnz_d) ||
-            dalloc(h, &A.mix_val_d, (size_t)A.mix_nnz_d) || dalloc(h, &A.mix_col_s, (size_t)A.mix_nnz_s) || dalloc(h, &A.mix_val_s, (size_t)A.mix_nnz_s)) return ITS_EHIP;
+        const size_t ne = (size_t)std::max<int64_t>(nnz, 1);
+        std::vector<int> rpd((size_t)n_rows + 1), rps((size_t)n_rows + 1), rph((size_t)n_rows + 1), cd(ne), cs(ne), ch(ne);
+        std::vector<double> vd(ne);
+        std::vector<float> vs(ne);
+        std::vector<uint16_t> vh(ne);
+        its_host::split_by_tiers(n_rows, row_ptr, col, val, h->mixed_mode, h->mixed_threshold, h->mixed_threshold2,
+                                 rpd.data(), cd.data(), vd.data(), rps.data(), cs.data(), vs.data(), rph.data(), ch.data(), vh.data());
+        A.mix_nnz_d = rpd[n_rows]; A.mix_nnz_s = rps[n_rows]; A.mix_nnz_h = rph[n_rows];
+        if (dalloc(h, &A.mix_rp_d, (size_t)n_rows + 1) || dalloc(h, &A.mix_rp_s, (size_t)n_rows + 1) || dalloc(h, &A.mix_rp_h, (size_t)n_rows + 1) ||
+            dalloc(h, &A.mix_col_d, (size_t)A.mix_nnz_d) || dalloc(h, &A.mix_val_d, (size_t)A.mix_nnz_d) ||
+            dalloc(h, &A.mix_col_s, (size_t)A.mix_nnz_s) || dalloc(h, &A.mix_val_s, (size_t)A.mix_nnz_s) ||
+            dalloc(h, &A.mix_col_h, (size_t)A.mix_nnz_h) || dalloc(h, &A.mix_val_h, (size_t)A.mix_nnz_h)) return ITS_EHIP;
         HIPCHK(h, hipMemcpy(A.mix_rp_d, rpd.data(), ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(A.mix_rp_s, rps.data(), ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(A.mix_rp_h, rph.data(), ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
         if (A.mix_nnz_d) {
             HIPCHK(h, hipMemcpy(A.mix_col_d, cd.data(), (size_t)A.mix_nnz_d * sizeof(int), hipMemcpyHostToDevice));
             HIPCHK(h, hipMemcpy(A.mix_val_d, vd.data(), (size_t)A.mix_nnz_d * sizeof(double), hipMemcpyHostToDevice));
@@ -412,6 +419,10 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         if (A.mix_nnz_s) {
             HIPCHK(h, hipMemcpy(A.mix_col_s, cs.data(), (size_t)A.mix_nnz_s * sizeof(int), hipMemcpyHostToDevice));
             HIPCHK(h, hipMemcpy(A.mix_val_s, vs.data(), (size_t)A.mix_nnz_s * sizeof(float), hipMemcpyHostToDevice));
+        }
+        if (A.mix_nnz_h) {
+            HIPCHK(h, hipMemcpy(A.mix_col_h, ch.data(), (size_t)A.mix_nnz_h * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(A.mix_val_h, vh.data(), (size_t)A.mix_nnz_h * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
         pt.lap("mixed-precision image");
     }
@@ -453,6 +464,15 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
         }
     }
     pt.lap("ELL image");
+    if (format == ITS_FMT_MIXED) {
+        // tiered sliced-ELL form of the split (its_ellm.hip) where the narrow ELL image exists; an extra — without it the
+        // products run on the CRS split
+        if (ellm_build(A, h->mixed_mode, h->mixed_threshold, h->mixed_threshold2, h->stream) != hipSuccess || !A.ellm_img) {
+            dfree(A.ellm_img); dfree(A.ellm_tier); dfree(A.ellm_off); A.ellm_bytes = 0;
+            (void)hipGetLastError();
+        }
+        pt.lap("tiered ELL image");
+    }
     if (which == ITS_MAT_A || which == ITS_MAT_U || which == ITS_MAT_DU) {
         // column-panel blocked image for large irregular matrices (its_panel.hip); crs_U for the b - U x pass of GS
         // (the image is an extra: when it cannot be built — its 12 bytes per entry or the sort's 24 do not fit — the matrix
@@ -499,7 +519,28 @@ extern "C" int its_set_mixed_threshold(its_handle *h, double threshold)
 {
     if (!h) return ITS_EINVAL;
     if (threshold != threshold) FAIL(h, ITS_EINVAL, "threshold is NaN");
-    h->mixed_threshold = threshold;
+    h->mixed_mode = ITS_AP_DP_SP; h->mixed_threshold = threshold; h->mixed_threshold2 = 0.0;
+    return ITS_OK;
+}
+
+extern "C" int its_set_mixed_mode(its_handle *h, int ap_value_type, double threshold_1, double threshold_2)
+{
+    if (!h) return ITS_EINVAL;
+    if (ap_value_type < ITS_AP_DP_SP || ap_value_type > ITS_AP_DP_SP_HP) FAIL(h, ITS_EINVAL, "ap_value_type: ITS_AP_DP_SP, _DP_HP, _SP_HP or _DP_SP_HP (config.mk:57)");
+    if (threshold_1 != threshold_1 || threshold_2 != threshold_2) FAIL(h, ITS_EINVAL, "threshold is NaN");
+    if (ap_value_type == ITS_AP_DP_SP_HP && threshold_2 > threshold_1) FAIL(h, ITS_EINVAL, "AP_THRESHOLD_2 must not exceed AP_THRESHOLD_1");
+    h->mixed_mode = ap_value_type; h->mixed_threshold = threshold_1; h->mixed_threshold2 = threshold_2;
+    return ITS_OK;
+}
+
+extern "C" int its_mixed_tiers(its_handle *h, int which, int64_t *nnz_by_tier, int64_t *value_bytes, int *ell_form)
+{
+    if (!h || which < 0 || which > 2) return ITS_EINVAL;
+    if (!h->have[which] || !h->mat[which].mix_rp_d) FAIL(h, ITS_ESTATE, "matrix was not uploaded with ITS_FMT_MIXED");
+    const CsrDev &A = h->mat[which];
+    if (nnz_by_tier) { nnz_by_tier[0] = A.mix_nnz_d; nnz_by_tier[1] = A.mix_nnz_s; nnz_by_tier[2] = A.mix_nnz_h; }
+    if (ell_form) *ell_form = A.ellm_img ? 1 : 0;
+    if (value_bytes) *value_bytes = A.ellm_img ? A.ellm_bytes : 8 * A.mix_nnz_d + 4 * A.mix_nnz_s + 2 * A.mix_nnz_h;
     return ITS_OK;
 }
 

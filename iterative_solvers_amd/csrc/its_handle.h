@@ -31,7 +31,10 @@ struct its_handle {
     CsrDev mat[4];
     bool have[4] = {false, false, false, false};
     int fmt = ITS_FMT_CSR_EXACT;          // format used by the solver loops for A
-    double mixed_threshold = 1.0;         // its_set_mixed_threshold: entries below it are stored in fp32 (ITS_FMT_MIXED)
+    // ITS_FMT_MIXED uploads (its_ap.h): storage mode (ITS_AP_*: the reference's AP_VALUE_TYPE) and its two magnitude
+    // thresholds (AP_THRESHOLD_1, AP_THRESHOLD_2 of config.mk:59-62); its_set_mixed_threshold = ITS_AP_DP_SP with threshold 1
+    int mixed_mode = 0;
+    double mixed_threshold = 1.0, mixed_threshold2 = 0.0;
 
     int n = 0;                            // owned rows
     int n_ext = 0;                        // owned + halo (== n on one GPU)

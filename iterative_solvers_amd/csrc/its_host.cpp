@@ -9,6 +9,7 @@
 // comparable iterates (SURVEY.md §7 "GS ordering").
 #include "../../include/its_hip.h"
 #include "its_hostplan.h"
+#include "its_ap.h"
 
 #include <algorithm>
 #include <cmath>
@@ -255,6 +256,30 @@ void split_by_magnitude(int n_rows, const int *rp, const int *col, const double 
         for (int k = rp[i]; k < rp[i + 1]; ++k) {
             if (!(std::abs(val[k]) < thr)) { col_d[d] = col[k]; val_d[d] = val[k]; ++d; }
             else { col_s[q] = col[k]; val_s[q] = (float)val[k]; ++q; }
+        }
+    }
+}
+
+void split_by_tiers(int n_rows, const int *rp, const int *col, const double *val, int mode, double t1, double t2,
+                    int *rp_d, int *col_d, double *val_d, int *rp_s, int *col_s, float *val_s,
+                    int *rp_h, int *col_h, uint16_t *val_h)
+{
+    rp_d[0] = 0; rp_s[0] = 0; rp_h[0] = 0;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_rows; ++i) {
+        int c[3] = {0, 0, 0};
+        for (int k = rp[i]; k < rp[i + 1]; ++k) ++c[its_ap::tier(val[k], mode, t1, t2)];
+        rp_d[i + 1] = c[0]; rp_s[i + 1] = c[1]; rp_h[i + 1] = c[2];
+    }
+    for (int i = 0; i < n_rows; ++i) { rp_d[i + 1] += rp_d[i]; rp_s[i + 1] += rp_s[i]; rp_h[i + 1] += rp_h[i]; }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_rows; ++i) {
+        int d = rp_d[i], q = rp_s[i], g = rp_h[i];
+        for (int k = rp[i]; k < rp[i + 1]; ++k) {
+            const int t = its_ap::tier(val[k], mode, t1, t2);
+            if (t == its_ap::TIER_FP64) { col_d[d] = col[k]; val_d[d] = val[k]; ++d; }
+            else if (t == its_ap::TIER_FP32) { col_s[q] = col[k]; val_s[q] = (float)val[k]; ++q; }
+            else { col_h[g] = col[k]; val_h[g] = its_ap::half_bits((float)val[k]); ++g; }
         }
     }
 }

@@ -30,6 +30,12 @@ void row_maxcol(int n_rows, const int *rp, const int *col, int limit, int *maxco
 void split_by_magnitude(int n_rows, const int *rp, const int *col, const double *val, double thr,
                         int *rp_d, int *col_d, double *val_d, int *rp_s, int *col_s, float *val_s);
 
+// split by storage tier (its_ap.h: mode, AP_THRESHOLD_1, AP_THRESHOLD_2): fp64 -> (rp_d, col_d, val_d), fp32 -> (rp_s, ...),
+// fp16 -> (rp_h, col_h, val_h as binary16 bits of the float-rounded value); same sizing and order rules as above
+void split_by_tiers(int n_rows, const int *rp, const int *col, const double *val, int mode, double t1, double t2,
+                    int *rp_d, int *col_d, double *val_d, int *rp_s, int *col_s, float *val_s,
+                    int *rp_h, int *col_h, uint16_t *val_h);
+
 // rows of A from the diagonal on (Gauss-Seidel, option "gs_prefix"): row i = (i, diag[i]) followed by row i of the strictly
 // upper part; rp sized n + 1, col / val sized nnz_U + n
 void assemble_diag_upper(int n, const int *u_rp, const int *u_col, const double *u_val, const double *diag,

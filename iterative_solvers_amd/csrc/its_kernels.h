@@ -90,6 +90,15 @@ struct CsrDev {
     double *mix_val_d = nullptr;
     float *mix_val_s = nullptr;
     int64_t mix_nnz_d = 0, mix_nnz_s = 0;
+    // third tier (its_ap.h: the "hp" modes of the reference's AP_VALUE_TYPE): binary16 bits of the float-rounded value
+    int *mix_rp_h = nullptr, *mix_col_h = nullptr;
+    uint16_t *mix_val_h = nullptr;
+    int64_t mix_nnz_h = 0;
+    // tiered sliced-ELL image of the same split (its_ellm.hip; matrices that hold the narrow ELL image): every (slice, slot)
+    // run of 128 values in the narrowest type its entries' tiers allow; tier word and start (in 256-byte units) per slice
+    unsigned char *ellm_img = nullptr;
+    uint32_t *ellm_tier = nullptr, *ellm_off = nullptr;
+    int64_t ellm_bytes = 0;
     // stream plan
     int n_blocks = 0;
     int4 *blk_desc = nullptr;                 // {first row, rows, first nnz, end nnz} per row block
@@ -185,6 +194,10 @@ int ell_tune(const char *name, int value);               // "spmv_ell", "spmv_el
 void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 void launch_spmv_mixed(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);   // EPI_STORE (+ dot), EPI_RESIDUAL
+// tiered sliced-ELL form of the mixed image (its_ellm.hip)
+hipError_t ellm_build(CsrDev &A, int mode, double t1, double t2, hipStream_t s);
+bool spmv_ellm_eligible(const CsrDev &A, const SpmvArgs &a, int epilogue);
+void launch_spmv_ellm(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // BLAS-1.  Reductions write ITS_NPART partials; reduce_finalize turns them into one scalar.

@@ -790,6 +790,7 @@ static int g_spmv_irr_grid = env_int("ITS_SPMV_IRR_GRID", 1280);
 static int g_spmv_irr_split = env_int("ITS_SPMV_IRR_SPLIT", 1);     // rows beyond a row block on the wave-per-row launch
 static int g_spmv_irr_len = env_int("ITS_SPMV_IRR_LEN", IRR_ROW_LEN);   // longest row above which it is used
 static int g_spmv_bigplan = env_int("ITS_SPMV_BIGPLAN", 1);     // 0 = spmv_stream4_kernel on the ordinary plan too
+static int g_mixed_ell = env_int("ITS_SPMV_MIXED_ELL", 1);       // 0 = the CRS split even where the tiered ELL image exists
 // the opt-in value-dictionary stream (2 bytes per nonzero) moves fewer bytes than the ELL image: it keeps its kernel
 bool spmv_valdict_selected(const CsrDev &A) { return g_spmv_valdict && g_spmv_idx && A.n_off > 0 && A.n_vals > 0 && A.max_row_len <= 8; }
 int spmv_tune(const char *name, int value)
@@ -804,6 +805,7 @@ int spmv_tune(const char *name, int value)
     if (!strcmp(name, "spmv_irr_len")) { if (value < 1) return -1; g_spmv_irr_len = value; return 0; }
     if (!strcmp(name, "spmv_irr_grid")) { if (value < 8 || value > ITS_NPART || (value & 7)) return -1; g_spmv_irr_grid = value; return 0; }
     if (!strcmp(name, "spmv_bigplan")) { if (value < 0 || value > 1) return -1; g_spmv_bigplan = value; return 0; }
+    if (!strcmp(name, "spmv_mixed_ell")) { if (value < 0 || value > 1) return -1; g_mixed_ell = value; return 0; }
     return -2;
 }
 
@@ -1086,7 +1088,8 @@ void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t
 template <int LPR, int EPI, bool DOT>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_mixed_kernel(
     int n_rows, const int *__restrict__ rp_d, const int *__restrict__ col_d, const double *__restrict__ val_d,
-    const int *__restrict__ rp_s, const int *__restrict__ col_s, const float *__restrict__ val_s, SpmvArgs a)
+    const int *__restrict__ rp_s, const int *__restrict__ col_s, const float *__restrict__ val_s,
+    const int *__restrict__ rp_h, const int *__restrict__ col_h, const _Float16 *__restrict__ val_h, SpmvArgs a)
 {
     __shared__ double s_red[4];
     constexpr int ROWS_PER_BLOCK = ITS_BLOCK / LPR;
@@ -1103,6 +1106,7 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_mixed_kernel(
         if (row < n_rows) {
             for (int j = rp_d[row] + sub, j1 = rp_d[row + 1]; j < j1; j += LPR) acc = fma(val_d[j], a.x[col_d[j]], acc);
             for (int j = rp_s[row] + sub, j1 = rp_s[row + 1]; j < j1; j += LPR) acc = fma((double)val_s[j], a.x[col_s[j]], acc);
+            if (rp_h) for (int j = rp_h[row] + sub, j1 = rp_h[row + 1]; j < j1; j += LPR) acc = fma((double)(float)val_h[j], a.x[col_h[j]], acc);
         }
 #pragma unroll
         for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, ITS_WAVE);
@@ -1134,7 +1138,7 @@ static void launch_mixed_lpr(const CsrDev &A, const SpmvArgs &a, int epi, hipStr
     dim3 g(ITS_NPART), b(ITS_BLOCK);
 #define ITS_LAUNCHM(E, D) \
     hipLaunchKernelGGL((spmv_mixed_kernel<LPR, E, D>), g, b, 0, s, A.n_rows, A.mix_rp_d, A.mix_col_d, A.mix_val_d, A.mix_rp_s, \
-                       A.mix_col_s, A.mix_val_s, a)
+                       A.mix_col_s, A.mix_val_s, A.mix_nnz_h ? A.mix_rp_h : nullptr, A.mix_col_h, reinterpret_cast<const _Float16 *>(A.mix_val_h), a)
     if (epi == EPI_RESIDUAL) ITS_LAUNCHM(EPI_RESIDUAL, false);
     else if (a.dotv) ITS_LAUNCHM(EPI_STORE, true);
     else ITS_LAUNCHM(EPI_STORE, false);
@@ -1143,6 +1147,7 @@ static void launch_mixed_lpr(const CsrDev &A, const SpmvArgs &a, int epi, hipStr
 
 void launch_spmv_mixed(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s)
 {
+    if (g_mixed_ell && spmv_ellm_eligible(A, a, epi)) { launch_spmv_ellm(A, a, epi, s); return; }
     switch (A.lanes_per_row) {
     case 2: launch_mixed_lpr<2>(A, a, epi, s); break;
     case 4: launch_mixed_lpr<4>(A, a, epi, s); break;
