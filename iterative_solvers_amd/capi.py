@@ -68,6 +68,7 @@ SIGNATURES = {
     "its_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_int_p, _c_dbl_p, _c_int_p]),
     "its_gmres_info": (C.c_int, [C.c_void_p, _c_int_p, _c_int_p]),
     "its_gs_info": (C.c_int, [C.c_void_p, _c_int_p, C.POINTER(C.c_int64), C.c_char_p, C.c_int]),
+    "its_sweep_info": (C.c_int, [C.c_void_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p]),
     "its_ell_info": (C.c_int, [C.c_void_p, C.c_int, _c_int_p, _c_int_p, C.POINTER(C.c_int64), _c_int_p]),
     "its_extract_diag": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "its_split_lu": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
@@ -311,6 +312,12 @@ class Handle:
         buf = C.create_string_buffer(64)
         self.check(self.L.its_gs_info(self.h, C.byref(r), C.byref(nz), buf, 64), "its_gs_info")
         return {"prefix_ready": bool(r.value), "nnz_du": nz.value, "kernel": buf.value.decode()}
+
+    def sweep_info(self):
+        """line-pipelined natural-order sweep (csrc/its_lines.hip): workgroups (0 = level schedule), line length, rows per chunk"""
+        w, a, c, nl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.check(self.L.its_sweep_info(self.h, C.byref(w), C.byref(a), C.byref(c), C.byref(nl)), "its_sweep_info")
+        return {"workgroups": w.value, "line_length": a.value, "rows_per_chunk": c.value, "n_levels": nl.value}
 
     # ---- device memory
     def dev_alloc(self, nbytes: int) -> int:

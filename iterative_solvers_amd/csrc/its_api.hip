@@ -37,6 +37,12 @@ struct PhaseTimer {
 
 int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp);    // its_panel.hip
 
+static void free_lines(its_handle *h)
+{
+    dfree(h->lines.img); dfree(h->lines.mimg); dfree(h->lines.counter);
+    h->lines = LinesPlan(); h->lines_ready = false;
+}
+
 static void free_level_ell(its_handle *h)
 {
     for (auto &v : h->level_ell) { dfree(v.val); dfree(v.idx); }
@@ -129,6 +135,7 @@ extern "C" int its_destroy(its_handle *h)
     (void)hipStreamSynchronize(h->stream);
     its_dist_destroy(h);
     for (auto &A : h->mat) free_csr(A);
+    free_lines(h);
     dfree(h->D); dfree(h->b); dfree(h->r); dfree(h->tmp); dfree(h->x_a); dfree(h->x_b); dfree(h->x);
     dfree(h->p); dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
     dfree(h->pcg_w); dfree(h->pcg_s); dfree(h->pcg_z); dfree(h->pcg_pair[0]); dfree(h->pcg_pair[1]); dfree(h->gram_part); dfree(h->gram_h); dfree(h->mgs_slots);
@@ -293,7 +300,7 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     }
     if (which == ITS_MAT_A) h->residual_done = false;
     if (which == ITS_MAT_L) {                     // the sweep schedule describes the old L
-        dfree(h->level_rows); dfree(h->sweep_desc); free_level_ell(h);
+        dfree(h->level_rows); dfree(h->sweep_desc); free_level_ell(h); free_lines(h);
         dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D); h->sw_w = 0;
         h->n_levels = 0; h->level_ptr.clear(); h->level_nshort.clear(); h->level_desc_first.clear(); h->level_desc_count.clear(); h->level_empty_lo.clear();
         h->L_rp.clear(); h->L_maxcol.clear();
@@ -621,6 +628,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->sweep_ell_levels = value;
         return ITS_OK;
     }
+    if (!strcmp(name, "sweep_lines")) {
+        if (value < 0 || value > 2) FAIL(h, ITS_EINVAL, "sweep_lines: 0 (level schedule), 1 (line-pipelined sweep where it pays: grids of one or two tiles) or 2 (wherever the matrix qualifies)");
+        h->sweep_lines = value;
+        return ITS_OK;
+    }
     if (!strcmp(name, "sweep_run")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_run: 0 or 1");
         h->sweep_run = value;
@@ -704,6 +716,17 @@ extern "C" int its_gs_info(its_handle *h, int *prefix_ready, int64_t *nnz_du, ch
     return ITS_OK;
 }
 
+extern "C" int its_sweep_info(its_handle *h, int *lines_workgroups, int *line_length, int *rows_per_chunk, int *n_levels)
+{
+    if (!h) return ITS_EINVAL;
+    if (n_levels) *n_levels = h->n_levels;
+    const bool on = h->lines_ready && h->sweep_lines && !h->lines_failed;
+    if (lines_workgroups) *lines_workgroups = on ? h->lines.nby * h->lines.nbz : 0;
+    if (line_length) *line_length = on ? h->lines.a : 0;
+    if (rows_per_chunk) *rows_per_chunk = on ? h->lines.ch : 0;
+    return ITS_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 static int spmv_dispatch(its_handle *h, const CsrDev &A, const SpmvArgs &a, int epi, int format)
 {
@@ -780,6 +803,7 @@ extern "C" int its_upload_vectors(its_handle *h, const double *D, const double *
     // the level-ordered copy of L carries the OLD diagonal: drop it (the next its_solver_setup rebuilds it; a bare
     // its_spltsv falls back to the level-list kernel, which reads D itself)
     dfree(h->sw_col); dfree(h->sw_val); dfree(h->sw_D); h->sw_w = 0;
+    free_lines(h);                                    // (so does the image of the line-pipelined sweep)
     return ITS_OK;
 }
 
@@ -1062,12 +1086,80 @@ static int build_gs_prefix(its_handle *h)
     return ITS_OK;
 }
 
+// Plan of the line-pipelined natural-order sweep (its_lines.hip) when crs_L is a stencil's: offsets {-1, -a} or {-1, -a, -b}
+// with a | b | n, a a multiple of 4, and every row verified on the device.  An extra: leaves lines_ready false otherwise.
+static int build_lines_plan(its_handle *h)
+{
+    free_lines(h);
+    static const bool env_off = getenv("ITS_SWEEP_LINES") && atoi(getenv("ITS_SWEEP_LINES")) == 0;
+    if (env_off || its_dist_active(h) || !h->have[ITS_MAT_L]) return ITS_OK;
+    const CsrDev &L = h->mat[ITS_MAT_L];
+    const int n = L.n_rows;
+    if (n < 64 || L.n_cols != n || L.n_off < 2 || L.n_off > 3 || !L.off_dict) return ITS_OK;
+    int dict[256];
+    if (hipMemcpy(dict, L.off_dict, sizeof dict, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return ITS_OK; }
+    std::sort(dict, dict + L.n_off);                          // most negative first
+    if (dict[L.n_off - 1] != -1) return ITS_OK;
+    const int64_t a = -(int64_t)dict[L.n_off - 2], b = L.n_off == 3 ? -(int64_t)dict[0] : 0;
+    if (a < 4 || (a & 3) || n % a) return ITS_OK;
+    if (b && (b <= a || b % a || n % b)) return ITS_OK;
+    LinesPlan P;
+    P.n = n; P.a = (int)a; P.b = (int)b;
+    P.ny = b ? (int)(b / a) : (int)(n / a);
+    P.nz = b ? (int)(n / b) : 1;
+    P.ch = 4;
+    if (b) { P.ty = std::min(16, P.ny); P.tz = std::min(256 / P.ty, P.nz); }
+    else { P.ty = std::min(256, P.ny); P.tz = 1; }
+    P.nby = (P.ny + P.ty - 1) / P.ty; P.nbz = (P.nz + P.tz - 1) / P.tz;
+    // measured (tools/lines_probe.py, tools/sweep_lines_ab.py): a win where one or two tiles hold the grid, a loss where the
+    // tiles form long chains (its_lines.hip); option value 2 takes it regardless
+    if (h->sweep_lines == 1 && (int64_t)P.nby * P.nbz > 2) return ITS_OK;
+    int *flags = nullptr;
+    auto give_up = [&]() { dfree(P.img); dfree(P.mimg); dfree(P.counter); dfree(flags); h->err.clear(); (void)hipGetLastError(); return ITS_OK; };
+    if (!h->D) return ITS_OK;
+    if (lines_image_doubles(P) > ((size_t)1 << 36)) return ITS_OK;
+    if (dalloc(h, &P.img, lines_image_doubles(P)) || dalloc(h, &P.mimg, lines_image_masks(P)) || dalloc(h, &P.counter, 8) || dalloc(h, &flags, 4)) return give_up();
+    if (hipMemsetAsync(flags, 0, 4 * sizeof(int), h->stream) != hipSuccess || hipMemsetAsync(P.counter, 0, 8 * sizeof(int), h->stream) != hipSuccess) return give_up();
+    launch_lines_build(P, L, h->D, flags, h->stream);
+    int hflags[4] = {1, 0, 0, 0};
+    if (hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return give_up();
+    if (hflags[0] & 1) return give_up();
+    dfree(flags);
+    P.fail = P.counter + 4;
+    P.fail_host = reinterpret_cast<unsigned long long *>(h->pinned + PIN_LINES);
+    *reinterpret_cast<volatile unsigned long long *>(P.fail_host) = 0ull;
+    h->lines = P; h->lines_ready = true; h->lines_failed = false;
+    if (getenv("ITS_DEBUG_LINES"))
+        fprintf(stderr, "its: line-pipelined sweep: lines of %d rows, %d x %d lines, tiles of %d x %d lines (%d workgroups), chunks of %d rows\n",
+                P.a, P.ny, P.nz, P.ty, P.tz, P.nby * P.nbz, P.ch);
+    return ITS_OK;
+}
+
+// the sweep's "gave up" word (pinned memory, written by sweep_lines_kernel): checked wherever the host has just waited
+static int check_lines_failure(its_handle *h)
+{
+    if (!h->lines_ready || !h->lines.fail_host) return ITS_OK;
+    if (*reinterpret_cast<volatile unsigned long long *>(h->lines.fail_host) == 0ull) return ITS_OK;
+    h->lines_failed = true;                                   // this handle stays on the level schedule from here on
+    *reinterpret_cast<volatile unsigned long long *>(h->lines.fail_host) = 0ull;
+    (void)hipMemsetAsync(h->lines.fail, 0, sizeof(int), h->stream);
+    FAIL(h, ITS_ESTATE, "the line-pipelined triangular sweep gave up waiting for a neighbouring tile (is the GPU shared or hung?): "
+                        "the iterate of this trip is invalid; option sweep_lines = 0 selects the level schedule");
+}
+
 // forward solve (D+L) x = rhs, level by level (kernels.hpp:451-473); x may alias rhs.  acc_out (may alias rhs): every row's
 // chain sum is stored there (SpmvArgs::acc_out)
 static int sweep(its_handle *h, double *x, const double *rhs, int first_level = 0, double *acc_out = nullptr)
 {
     const CsrDev &L = h->mat[ITS_MAT_L];
     const bool dist = its_dist_active(h);
+    // stencil matrices in natural order: the whole sweep as one launch pipelined over grid lines (its_lines.hip); it presets
+    // x, so not for the in-place sweeps of the preconditioner (x == rhs)
+    if (h->lines_ready && h->sweep_lines && !h->lines_failed && !dist && first_level == 0 && x != rhs && h->D) {
+        launch_sweep_lines(h->lines, x, rhs, acc_out, h->stream);
+        HIPCHK(h, hipGetLastError());
+        return ITS_OK;
+    }
     for (int l = first_level; l < h->n_levels; ++l) {
         const int cnt = h->level_ptr[l + 1] - h->level_ptr[l];
         if (h->level_empty_lo[l] >= 0 && h->sweep_stream) {
@@ -1137,6 +1229,8 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         }
         if (rc) return rc;
         pt.lap("sweep schedule");
+        if ((rc = build_lines_plan(h))) return rc;
+        pt.lap("line-pipelined sweep plan");
         if (solver_kind == ITS_GAUSS_SEIDEL && (rc = build_gs_prefix(h))) return rc;
     }
     pt.lap("image of D + U (gs_prefix)");
@@ -1652,7 +1746,7 @@ extern "C" int its_iterate(its_handle *h, int iter_count, double *residual_norm)
         HIPCHK(h, hipStreamSynchronize(h->stream));
     } else if ((rc = wait_pinned_word(h, slot))) return rc;
     *residual_norm = h->last_residual = *slot;
-    return ITS_OK;
+    return check_lines_failure(h);
 }
 
 extern "C" int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double *residuals)
@@ -1708,7 +1802,7 @@ extern "C" int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double
         h->prof_spmv_ms = (float)(tot / h->prof_n);
     }
     h->last_residual = residuals[n_trips - 1];
-    return ITS_OK;
+    return check_lines_failure(h);
 }
 
 extern "C" int its_gmres_restart(its_handle *h, int iter_count)
@@ -1965,11 +2059,12 @@ extern "C" int its_spltsv(its_handle *h, double *x_dev, const double *rhs_dev)
             if (h->L_maxcol[i] >= i) FAIL(h, ITS_EINVAL, "crs_L must be strictly lower triangular");
         int rc = build_levels(h, n);
         if (rc) return rc;
+        if ((rc = build_lines_plan(h))) return rc;
     }
     int rc = sweep(h, x_dev, rhs_dev);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return ITS_OK;
+    return check_lines_failure(h);
 }
 
 extern "C" int its_dev_alloc(its_handle *h, void **p, size_t bytes)

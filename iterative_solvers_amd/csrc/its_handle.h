@@ -130,6 +130,11 @@ struct its_handle {
     int sweep_run = 1;
     int *level_rows = nullptr;            // device
     int n_levels = 0;
+    // natural-order sweep of a stencil matrix as one launch pipelined over grid lines (its_lines.hip; option "sweep_lines"):
+    // built by its_solver_setup when crs_L's offsets are {-1, -a[, -b]} and every row passes the device check
+    LinesPlan lines;
+    bool lines_ready = false, lines_failed = false;
+    int sweep_lines = 1;
     // multicolour permutation (gs_order == ITS_GS_MULTICOLOR): new index -> old index
     std::vector<int> mc_perm, mc_iperm;
 
@@ -137,6 +142,7 @@ struct its_handle {
 };
 
 constexpr int ITS_MAT_DU = 3;             // its_handle::mat slot of the D + U image (internal)
+constexpr size_t PIN_LINES = 9;           // "the line-pipelined sweep gave up" word inside its_handle::pinned
 constexpr size_t PIN_RES = 8;             // index of the residual word inside its_handle::pinned
 constexpr size_t PIN_REGIONS = 16;        // first index of the restart-length-sized regions
 

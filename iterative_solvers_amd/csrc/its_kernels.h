@@ -282,4 +282,21 @@ void launch_sweep_ell_run(int n, int W, int l0, int l1, const int *level_ptr_dev
 void launch_sweep_ell_level(int n, int W, int p0, int p1, const int *rows, const int *sw_col, const double *sw_val,
                             const double *sw_D, double *x, const double *rhs, hipStream_t s, double *acc_out = nullptr);
 
+// ---------------------------------------------------------------------------------------
+// Natural-order sweep of a stencil matrix as ONE launch, a wavefront pipelined over grid lines (its_lines.hip).
+// a = rows per line, b = rows per plane (0: 2-D), ny x nz lines, tiles of ty x tz lines per workgroup, ch rows per chunk;
+// lv = the entries of L in three fixed slots (offset -b, -a, -1), slot-major; mask = presence bits per row.
+// ---------------------------------------------------------------------------------------
+struct LinesPlan {
+    int n = 0, a = 0, b = 0, ny = 0, nz = 0, ty = 0, tz = 0, nby = 0, nbz = 0, ch = 0;
+    double *img = nullptr;                            // operands in the order the sweep consumes them (its_lines.hip)
+    unsigned int *mimg = nullptr;                     // presence bits per chunk
+    int *counter = nullptr, *fail = nullptr;          // tile counter; sticky "a poll gave up" flag (device)
+    unsigned long long *fail_host = nullptr;          // the same, in pinned host memory (what the host checks)
+};
+size_t lines_image_doubles(const LinesPlan &P);
+size_t lines_image_masks(const LinesPlan &P);
+void launch_lines_build(const LinesPlan &P, const CsrDev &L, const double *D, int *flags, hipStream_t s);
+void launch_sweep_lines(const LinesPlan &P, double *x, const double *rhs, double *acc_out, hipStream_t s);
+
 }  // namespace its

@@ -16,7 +16,12 @@ SPMV_FORMAT = crs
 # [shipped, ref]             Jacobi sweep: shipped = bug-compatible with methods/jacobi.hpp:191,
 #                            ref = jacobi_iteration_ref_cpu (correct)
 JACOBI_MODE = shipped
-# [level, multicolor]        Gauss-Seidel sweep order
+# [level, multicolor, auto]  Gauss-Seidel sweep order.  level = the reference's natural order (methods/gauss_seidel.hpp:227,
+#                            kernels.hpp:451-473), the iteration every golden output was recorded with.  multicolor = the
+#                            same sweep on P A P^T, rows colour by colour: a different (documented) iteration, 8x faster
+#                            per trip on a large 3-D stencil, whose natural order is one launch per grid hyperplane.
+#                            auto = level unless the natural order has more than 600 dependency levels on a matrix
+#                            of a million rows or more (then multicolor; its_solve says so on stderr).
 GS_ORDER = level
 # [dense, fast]              GMRES least squares on the host: dense = the reference's (m+1)^2
 #                            products (its stopping behaviour at TOL=1e-14 exactly), fast = O(m) rotations

@@ -29,6 +29,7 @@ void preprocessing(argType *args, Solver<VT> *solver)
     solver->init_residual(&r0_inf, &r0_two);                                     // main.cpp:307
     solver->gmres_restart_length = args->loop_params.gmres_restart_len;
     solver->init_structs();                                                      // main.cpp:317
+    solver->hint_sweep_order();                // (stderr only: stdout stays the reference's)
     args->loop_params.stopping_criteria = args->loop_params.compute_stopping_criteria(args->solver_type, r0_inf, r0_two);   // :319
     args->timers.preprocessing_wtime.end_stopwatch();
 }
@@ -44,7 +45,7 @@ void run_solver(int argc, char *argv[])
     if (const char *e = getenv("ITS_TOL")) args->loop_params.tol = atof(e);
     if (const char *e = getenv("ITS_GMRES_RESTART_LEN")) args->loop_params.gmres_restart_len = atoi(e);
     Solver<VT> *solver = new Solver<VT>(args->solver_type, args->preconditioner_type);
-    if (const char *e = getenv("ITS_GS_ORDER")) solver->gs_order = std::string(e) == "multicolor" ? ITS_GS_MULTICOLOR : ITS_GS_LEVEL;
+    if (const char *e = getenv("ITS_GS_ORDER")) solver->gs_order = std::string(e) == "multicolor" ? ITS_GS_MULTICOLOR : std::string(e) == "auto" ? Solver<VT>::GS_ORDER_AUTO : ITS_GS_LEVEL;
     std::cout << "Reading Matrix" << std::endl;
     read_mtx(args->matrix_file_name, &args->coo_mat);
     preprocessing<VT>(args, solver);

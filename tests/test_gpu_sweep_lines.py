@@ -1,0 +1,122 @@
+"""The natural-order triangular sweep of a stencil matrix as ONE launch, a wavefront pipelined over grid lines
+(csrc/its_lines.hip, option "sweep_lines"), against the level schedule it replaces and against the oracle.
+
+spltsv_crs (kernels.hpp:451-473) is sequential; both schedules hand every row the operands the sequential loop would and
+run the row's fused multiply-adds in CRS order from 0.0, so the iterates must be BIT-identical: to each other (option 0)
+and to the oracle's Gauss-Seidel.  Grids are chosen so that tiles are ragged in both directions, lines are multiples of 4 but not of 8
+rows, and tiles poll their neighbours' lines through memory (more than one tile per direction)."""
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from iterative_solvers_amd import capi, matgen, solver as S
+
+pytestmark = pytest.mark.gpu
+
+GRIDS = {
+    "lap2d_64": lambda: matgen.laplace2d_5pt(64),
+    "lap2d_200": lambda: matgen.laplace2d_5pt(200),
+    "lap2d_520": lambda: matgen.laplace2d_5pt(520),          # 520 lines: three tiles of 256 lanes, the last ragged
+    "lap2d_12": lambda: matgen.laplace2d_5pt(12),            # three chunks per line
+    "lap3d_16": lambda: matgen.laplace3d_7pt(16),
+    "lap3d_40": lambda: matgen.laplace3d_7pt(40),            # 40 x 40 lines: 3 x 3 tiles of 16 x 16, ragged
+    "lap3d_24x5": lambda: matgen.laplace3d_7pt(24, 5),       # fewer planes than a tile is deep
+    "lap3d_12": lambda: matgen.laplace3d_7pt(12),
+    "lap3d_64x20": lambda: matgen.laplace3d_7pt(64, 20),
+}
+
+
+def run_gs(rp, col, val, lines, trips=12, x0=None, b=None):
+    n = len(rp) - 1
+    args = S.Args("gauss-seidel", S.LoopParams(max_iters=trips, tol=1e-300), S.Flags(), "", "none")
+    sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_LEVEL)
+    try:
+        sol.handle.set_option("sweep_lines", 2 * lines)           # 2: wherever the matrix qualifies (1 = only where it is faster)
+        S.preprocessing_crs(args, sol, rp, col, val, np.ones(n) if b is None else b, np.zeros(n) if x0 is None else x0)
+        info = sol.handle.sweep_info()
+        S.solve(args, sol)
+        return args.normed_residuals[:args.loop_params.residual_count].copy(), sol.x_star.copy(), info
+    finally:
+        sol.handle.close()
+
+
+@pytest.mark.parametrize("grid", sorted(GRIDS))
+def test_line_sweep_equals_level_schedule_and_oracle(grid):
+    rp, col, val = GRIDS[grid]()
+    n = len(rp) - 1
+    rng = np.random.default_rng(9)
+    # random coefficients on the stencil's pattern (diagonally dominant), random right-hand side and start
+    val = val * rng.uniform(0.5, 1.5, len(val))
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    dg = rows == col
+    off_sum = np.zeros(n); np.add.at(off_sum, rows[~dg], np.abs(val[~dg]))
+    val[dg] = 1.0 + off_sum
+    b = rng.uniform(-1, 1, n); x0 = rng.uniform(-1, 1, n)
+    on = run_gs(rp, col, val, 1, x0=x0, b=b)
+    off = run_gs(rp, col, val, 0, x0=x0, b=b)
+    assert on[2]["workgroups"] >= 1 and off[2]["workgroups"] == 0
+    assert on[2]["rows_per_chunk"] == 4 and on[2]["line_length"] % 4 == 0
+    assert np.array_equal(on[1], off[1])
+    assert np.array_equal(on[0], off[0])                     # the recording pass is the same launch either way
+    orc.set_threads(1)
+    ref = orc.solve(rp, col, val, b, x0, orc.GAUSS_SEIDEL, max_iters=12, tol=1e-300)
+    assert np.array_equal(on[1], ref["x_star"])
+
+
+def test_matrices_that_are_not_line_stencils_keep_the_level_schedule():
+    # 27-point stencil (offsets beyond the three), a line length that is no multiple of 4, a periodic wrap-around entry
+    for rp, col, val in (matgen.convdiff3d_27pt(8), matgen.laplace2d_5pt(33)):
+        assert run_gs(rp, col, val, 1, trips=4)[2]["workgroups"] == 0
+    rp, col, val = matgen.laplace2d_5pt(16)
+    col = col.copy()
+    # row 16 (first row of the second line) reads row 15 (last row of the first line) instead of nothing: offset -1 across a
+    # line start — same dictionary, but not the grid's dependency structure
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    k = np.where((rows == 32) & (col == 16))[0][0]
+    col[k] = 31
+    order = np.lexsort((col, rows)); col = col[order]; val = val[order]
+    on = run_gs(rp, col, val, 1, trips=4)
+    off = run_gs(rp, col, val, 0, trips=4)
+    assert on[2]["workgroups"] == 0 and np.array_equal(on[1], off[1])
+
+
+def test_spltsv_entry_point_takes_the_line_sweep(gpu_handle):
+    """its_spltsv (kernels.hpp:451-473 alone) on a stencil's strictly lower part, x and rhs apart: the line sweep; the
+    oracle's forward substitution bit for bit."""
+    h = gpu_handle
+    h.set_option("sweep_lines", 2)
+    rp, col, val = matgen.laplace3d_7pt(24)
+    n = len(rp) - 1
+    (Lp, Lc, Lv), _ = capi.split_lu(rp, col, val)
+    D = capi.extract_diag(rp, col, val)
+    rhs = np.random.default_rng(4).uniform(-1, 1, n)
+    h.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_CSR_EXACT)
+    h.upload_crs(Lp, Lc, Lv, capi.MAT_L, capi.FMT_CSR_EXACT)
+    h.upload_vectors(D, rhs, np.zeros(n))
+    px = h.to_dev(np.zeros(n)); pr = h.to_dev(rhs)
+    try:
+        h.spltsv(px, pr)
+        x = h.from_dev(px, n)
+        assert h.sweep_info()["workgroups"] >= 1
+        assert np.array_equal(x, orc.spltsv(Lp, Lc, Lv, D, rhs))
+        h.spltsv(pr, pr)                                     # in place (the preconditioner's form): the level schedule
+        assert np.array_equal(h.from_dev(pr, n), x)
+    finally:
+        h.dev_free(px); h.dev_free(pr)
+        h.set_option("sweep_lines", 1)
+
+
+def test_default_takes_the_line_sweep_for_grids_of_one_or_two_tiles_only():
+    for gen, want in ((lambda: matgen.laplace2d_5pt(256), True), (lambda: matgen.laplace2d_5pt(520), False),
+                      (lambda: matgen.laplace3d_7pt(16), True), (lambda: matgen.laplace3d_7pt(40), False)):
+        rp, col, val = gen()
+        n = len(rp) - 1
+        args = S.Args("gauss-seidel", S.LoopParams(max_iters=3, tol=1e-300), S.Flags(), "", "none")
+        sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_LEVEL)
+        try:
+            S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.zeros(n))
+            info = sol.handle.sweep_info()
+            assert (info["workgroups"] > 0) == want and info["n_levels"] > 1
+        finally:
+            sol.handle.close()
