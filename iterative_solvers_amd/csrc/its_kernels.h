@@ -291,11 +291,15 @@ struct LinesPlan {
     int n = 0, a = 0, b = 0, ny = 0, nz = 0, ty = 0, tz = 0, nby = 0, nbz = 0, ch = 0;
     double *img = nullptr;                            // operands in the order the sweep consumes them (its_lines.hip)
     unsigned int *mimg = nullptr;                     // presence bits per chunk
+    double *rimg = nullptr, *ximg = nullptr;          // per sweep: right-hand side packed into, x produced in, the same order
+    int *sbase = nullptr;                             // chunks of a tile before step S (the order's index, its_lines.hip)
     int *counter = nullptr, *fail = nullptr;          // tile counter; sticky "a poll gave up" flag (device)
     unsigned long long *fail_host = nullptr;          // the same, in pinned host memory (what the host checks)
 };
 size_t lines_image_doubles(const LinesPlan &P);
 size_t lines_image_masks(const LinesPlan &P);
+int lines_steps(const LinesPlan &P);
+void lines_step_bases(const LinesPlan &P, int *sbase);
 void launch_lines_build(const LinesPlan &P, const CsrDev &L, const double *D, int *flags, hipStream_t s);
 void launch_sweep_lines(const LinesPlan &P, double *x, const double *rhs, double *acc_out, hipStream_t s);
 

@@ -31,7 +31,7 @@ def run_gs(rp, col, val, lines, trips=12, x0=None, b=None):
     args = S.Args("gauss-seidel", S.LoopParams(max_iters=trips, tol=1e-300), S.Flags(), "", "none")
     sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_LEVEL)
     try:
-        sol.handle.set_option("sweep_lines", 2 * lines)           # 2: wherever the matrix qualifies (1 = only where it is faster)
+        sol.handle.set_option("sweep_lines", lines)               # 0: the level schedule; 1 (default): the line sweep wherever the matrix qualifies
         S.preprocessing_crs(args, sol, rp, col, val, np.ones(n) if b is None else b, np.zeros(n) if x0 is None else x0)
         info = sol.handle.sweep_info()
         S.solve(args, sol)
@@ -85,7 +85,6 @@ def test_spltsv_entry_point_takes_the_line_sweep(gpu_handle):
     """its_spltsv (kernels.hpp:451-473 alone) on a stencil's strictly lower part, x and rhs apart: the line sweep; the
     oracle's forward substitution bit for bit."""
     h = gpu_handle
-    h.set_option("sweep_lines", 2)
     rp, col, val = matgen.laplace3d_7pt(24)
     n = len(rp) - 1
     (Lp, Lc, Lv), _ = capi.split_lu(rp, col, val)
@@ -104,12 +103,12 @@ def test_spltsv_entry_point_takes_the_line_sweep(gpu_handle):
         assert np.array_equal(h.from_dev(pr, n), x)
     finally:
         h.dev_free(px); h.dev_free(pr)
-        h.set_option("sweep_lines", 1)
 
 
-def test_default_takes_the_line_sweep_for_grids_of_one_or_two_tiles_only():
-    for gen, want in ((lambda: matgen.laplace2d_5pt(256), True), (lambda: matgen.laplace2d_5pt(520), False),
-                      (lambda: matgen.laplace3d_7pt(16), True), (lambda: matgen.laplace3d_7pt(40), False)):
+def test_default_takes_the_line_sweep_wherever_the_matrix_qualifies():
+    for gen, want in ((lambda: matgen.laplace2d_5pt(256), True), (lambda: matgen.laplace2d_5pt(520), True),
+                      (lambda: matgen.laplace3d_7pt(16), True), (lambda: matgen.laplace3d_7pt(40), True),
+                      (lambda: matgen.convdiff3d_27pt(8), False), (lambda: matgen.powerlaw(3000), False)):
         rp, col, val = gen()
         n = len(rp) - 1
         args = S.Args("gauss-seidel", S.LoopParams(max_iters=3, tol=1e-300), S.Flags(), "", "none")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Line-pipelined sweep: trip time on rectangular 2-D grids (ny lines of nx rows) — separates the effect of the line length
-(the stride between the lanes' rows) from that of the number of tiles.  usage: lines_probe.py ny nx [ny nx ...]"""
+(the stride between the lanes' rows) from that of the number of tiles.  usage: lines_probe.py <ny nx | NZxNYxNX> ..."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,10 +8,19 @@ sys.path.insert(0, ROOT)
 from iterative_solvers_amd import capi, matgen, solver as S
 TRIPS = int(os.environ.get("TRIPS", "10"))
 a = sys.argv[1:]
-for ny, nx in zip(a[0::2], a[1::2]):
-    ny, nx = int(ny), int(nx)
-    offs = [(0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0)]
-    rp, col, val = matgen._stencil_crs((1, ny, nx), offs, [-1.0, -1.0, 4.0, -1.0, -1.0])
+grids = []
+while a:
+    if "x" in a[0]:                                          # NZxNYxNX: a 3-D grid (7-point)
+        grids.append(tuple(int(v) for v in a.pop(0).split("x")))
+    else:
+        grids.append((1, int(a.pop(0)), int(a.pop(0))))
+for nz, ny, nx in grids:
+    if nz == 1:
+        offs = [(0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0)]
+        rp, col, val = matgen._stencil_crs((1, ny, nx), offs, [-1.0, -1.0, 4.0, -1.0, -1.0])
+    else:
+        offs = [(-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0)]
+        rp, col, val = matgen._stencil_crs((nz, ny, nx), offs, [-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0])
     n = len(rp) - 1
     for lines in (1, 0):
         args = S.Args("gauss-seidel", S.LoopParams(max_iters=10**9, tol=0.0))
@@ -25,6 +34,6 @@ for ny, nx in zip(a[0::2], a[1::2]):
         h.synchronize()
         ms = (time.perf_counter() - t0) / TRIPS * 1e3
         info = h.sweep_info()
-        steps = nx // 4 + ny if lines else 0
-        print("%d lines of %d rows, sweep_lines %d: %.4f ms/trip%s" % (ny, nx, lines, ms, (", %d tiles, %.2f us per critical step" % (info["workgroups"], ms * 1e3 / steps)) if lines else ""), flush=True)
+        steps = nx // 4 + ny + nz - 1 if lines else 0
+        print("%d lines of %d rows, sweep_lines %d: %.4f ms/trip%s" % (ny * nz, nx, lines, ms, (", %d tiles, %.2f us per critical step" % (info["workgroups"], ms * 1e3 / steps)) if lines else ""), flush=True)
         h.close()
