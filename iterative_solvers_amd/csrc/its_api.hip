@@ -1127,6 +1127,8 @@ static int build_lines_plan(its_handle *h)
     int hflags[4] = {1, 0, 0, 0};
     if (hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return give_up();
     if (hflags[0] & 1) return give_up();
+    static const bool env_masked = getenv("ITS_LINES_MASKED") && atoi(getenv("ITS_LINES_MASKED")) != 0;
+    P.masked = (hflags[0] & 2) != 0 || env_masked;
     dfree(flags);
     P.fail = P.counter + 4;
     P.fail_host = reinterpret_cast<unsigned long long *>(h->pinned + PIN_LINES);

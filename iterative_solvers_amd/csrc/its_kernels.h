@@ -292,6 +292,7 @@ struct LinesPlan {
     double *img = nullptr;                            // operands in the order the sweep consumes them (its_lines.hip)
     unsigned int *mimg = nullptr;                     // presence bits per chunk
     double *rimg = nullptr, *ximg = nullptr;          // per sweep: right-hand side packed into, x produced in, the same order
+    bool masked = true;                               // rows with entries missing inside the grid: presence bits decide (its_lines.hip)
     int *sbase = nullptr;                             // chunks of a tile before step S (the order's index, its_lines.hip)
     int *counter = nullptr, *fail = nullptr;          // tile counter; sticky "a poll gave up" flag (device)
     unsigned long long *fail_host = nullptr;          // the same, in pinned host memory (what the host checks)

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(LINES_WG) void lines_build_kernel(
     LnWhere ws[LN_G];
     ln_where(g, blockIdx.x, t, ws, s_w);
     const int NA = g.b > 0 ? 4 : 3;
-    bool bad = false;
+    bool bad = false, holes = false;
     for (int j = 0; j < LN_G; ++j) {
         const LnWhere &w = ws[j];
         if (!w.active) continue;
@@ -153,6 +153,10 @@ __global__ __launch_bounds__(LINES_WG) void lines_build_kernel(
                     if (slot < 0 || (m >> slot & 1)) { bad = true; continue; }
                     m |= 1 << slot; v[slot] = val[jj];
                 }
+                // a row without an entry where the grid has the neighbour: the sweep must skip it by its presence bit
+                // (flags[0] & 2); without such rows absent entries are stored as 0.0 and meet operands that are finite
+                const int full = (p >= 1 ? 4 : 0) | (w.y >= 1 ? 2 : 0) | ((g.b > 0 && w.z >= 1) ? 1 : 0);
+                holes |= m != full;
             }
             const size_t plane = (size_t)w.cnt * 2, e = (size_t)(u >> 1) * plane + (u & 1);
             int k = 0;
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(LINES_WG) void lines_build_kernel(
         mimg[w.slot0 + w.rank] = mword;
     }
     if (bad) atomicOr(flags, 1);
+    if (holes) atomicOr(flags, 2);
 }
 
 // In front of every sweep: the right-hand side into that order (rimg); in the sweep's output buffer (ximg, same order) the
@@ -246,7 +251,7 @@ struct LnSet { double v0[LN_CH], v1[LN_CH], v2[LN_CH], dd[LN_CH], rr[LN_CH]; uns
 
 // Addresses as (uniform base) + (32-bit lane offset): the bases live in scalar registers and the loads take them as such —
 // a lane in this kernel is alone on its SIMD, every vector instruction it does not issue is time off the step.
-template <bool HAVE_B>
+template <bool HAVE_B, bool MASKED>
 __device__ __forceinline__ void ln_load(LnSet &c, size_t tile_slot0, const LnPos &p, const double *__restrict__ img, const unsigned int *__restrict__ mimg,
                                         const double *__restrict__ rimg)
 {
@@ -270,7 +275,7 @@ __device__ __forceinline__ void ln_load(LnSet &c, size_t tile_slot0, const LnPos
         c.v1[u] = q1.x; c.v1[u + 1] = q1.y; c.v2[u] = q2.x; c.v2[u + 1] = q2.y;
         c.dd[u] = qd.x; c.dd[u + 1] = qd.y; c.rr[u] = qr.x; c.rr[u + 1] = qr.y;
     }
-    c.m = __builtin_nontemporal_load(reinterpret_cast<const unsigned int *>(reinterpret_cast<const char *>(mimg) + slot0 * 4 + (vo >> 2)));
+    c.m = MASKED ? __builtin_nontemporal_load(reinterpret_cast<const unsigned int *>(reinterpret_cast<const char *>(mimg) + slot0 * 4 + (vo >> 2))) : 0u;
 }
 
 // The slow path of a poll — load again and wait — as inline asm, invisible to the compiler's wait-count bookkeeping (a
@@ -291,7 +296,12 @@ __device__ __forceinline__ int lines_ld_agent_int(const void *p)
 // barrier that orders LDS only: __syncthreads would also wait for every global load and store in flight
 __device__ __forceinline__ void ln_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool HAVE_B, bool HAVE_ACC>
+// MASKED: rows may lack an entry where the grid has the neighbour (presence bits decide, as everywhere before this
+// variant existed).  Otherwise the only absent entries are those of rows on the grid's low faces: stored as 0.0 they
+// multiply an operand that is made finite for them — zeros from the edge wave for the lines at y = 0 / z = 0, xprev reset at
+// the head of a line — and fma(0.0, finite, acc) == acc bit for bit (acc is never -0.0: it starts from +0.0), which
+// saves the 15 selects and tests per row-triple of a step.
+template <bool HAVE_B, bool HAVE_ACC, bool MASKED>
 __global__ __launch_bounds__(LINES_THREADS) void sweep_lines_kernel(
     LinesGeom g, const double *__restrict__ img, const unsigned int *__restrict__ mimg, int *counter, int *fail,
     unsigned long long *fail_host, double *ximg, const double *__restrict__ rimg, double *acc_out)
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(LINES_THREADS) void sweep_lines_kernel(
         const size_t tile_slot0 = (size_t)tile * nq * LINES_WG;
         LnPos pi;                                        // the place of the step whose operands are requested next
         ln_pos_first<!HAVE_B>(pi, ty, tz, g.ty, g.tz);
-#define LN_ISSUE(I, T) { ln_load<HAVE_B>(set[I], tile_slot0, pi, img, mimg, rimg); if (pi.S + 1 < nsteps) ln_pos_next<!HAVE_B>(pi, ty, tz, g.ty, g.tz, nq); }
+#define LN_ISSUE(I, T) { ln_load<HAVE_B, MASKED>(set[I], tile_slot0, pi, img, mimg, rimg); if (pi.S + 1 < nsteps) ln_pos_next<!HAVE_B>(pi, ty, tz, g.ty, g.tz, nq); }
         LN_ISSUE(0, 0) LN_ISSUE(1, 1) LN_ISSUE(2, 2) LN_ISSUE(3, 3)
         static_assert(LN_K == 5, "the step loop is unrolled by hand");
         ln_barrier();                                    // (the edge wave has written the chunks of step 0)
@@ -353,14 +363,15 @@ __global__ __launch_bounds__(LINES_THREADS) void sweep_lines_kernel(
                 /* the row's chain in CRS order: -b, -a, -1 (ascending columns), from 0.0 */                      \
                 const unsigned int m = (c.m >> (8 * u)) & 255u;                                                   \
                 double acc = 0.0;                                                                                 \
-                if (HAVE_B && (m & 1u)) acc = fma(c.v0[u], xb[u], acc);                                           \
-                if (m & 2u) acc = fma(c.v1[u], xa[u], acc);                                                       \
-                if (m & 4u) acc = fma(c.v2[u], xprev, acc);                                                       \
+                if (HAVE_B && (!MASKED || (m & 1u))) acc = fma(c.v0[u], xb[u], acc);                              \
+                if (!MASKED || (m & 2u)) acc = fma(c.v1[u], xa[u], acc);                                          \
+                if (!MASKED || (m & 4u)) acc = fma(c.v2[u], xprev, acc);                                          \
                 xprev = (c.rr[u] - acc) / c.dd[u];                                                                \
                 out[u] = xprev;                                                                                   \
                 if (HAVE_ACC && act) acc_out[r0 + u] = acc;                                                       \
             }                                                                                                     \
             _Pragma("unroll") for (int u = 0; u < LN_CH; ++u) s_c[buf][t][u] = out[u];                            \
+            if (!MASKED && (q < 0 || q >= nq)) xprev = 0.0;        /* (a line's first row has no -1 entry: 0.0 times this) */ \
             if (act) {                                                                                            \
                 char *xo = reinterpret_cast<char *>(ximg) + c.slot0 * 32;                                         \
                 const size_t plane_b = (size_t)c.cnt * 16;                                                        \
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(LINES_THREADS) void sweep_lines_kernel(
                                  "+v"(pf[2][0]), "+v"(pf[2][1]), "+v"(pf[2][2]), "+v"(pf[2][3]), "+v"(pf[3][0]), "+v"(pf[3][1]), "+v"(pf[3][2]), "+v"(pf[3][3]) :: "memory"); \
                 }                                                                                                 \
             }                                                                                                     \
-            if (e < LN_EDGE) { _Pragma("unroll") for (int u = 0; u < LN_CH; ++u) s_c[((T) + 1) & 1][LINES_WG + es][u] = pf[I][u]; } }
+            if (e < LN_EDGE) { _Pragma("unroll") for (int u = 0; u < LN_CH; ++u) s_c[((T) + 1) & 1][LINES_WG + es][u] = have ? pf[I][u] : 0.0; } }
         static_assert(LN_CH * (LN_KE - 1) == 12, "the hand-counted wait above");
         // Pacing.  A request travels LN_KE steps ahead of its use, so this tile runs without re-polls only once it is
         // (TY - 1) + LN_KE steps + a memory round trip behind its neighbour.  Started as soon as chunk 0 is there, it gets
@@ -531,8 +542,9 @@ void launch_sweep_lines(const LinesPlan &P, double *x, const double *rhs, double
     const int tiles = P.nby * P.nbz;
     const unsigned blocks = (unsigned)((int64_t)tiles * ((lines_steps(P) + LN_G - 1) / LN_G));
     hipLaunchKernelGGL(lines_pack_kernel, dim3(blocks), dim3(LINES_WG), 0, s, g, rhs, P.rimg, reinterpret_cast<unsigned long long *>(P.ximg), P.counter);
-#define ITS_LAUNCHLN(B, A) \
-    hipLaunchKernelGGL((sweep_lines_kernel<B, A>), dim3(tiles), dim3(LINES_THREADS), 0, s, g, P.img, P.mimg, P.counter, P.fail, P.fail_host, P.ximg, P.rimg, acc_out)
+#define ITS_LAUNCHLN(B, A) do { \
+    if (P.masked) hipLaunchKernelGGL((sweep_lines_kernel<B, A, true>), dim3(tiles), dim3(LINES_THREADS), 0, s, g, P.img, P.mimg, P.counter, P.fail, P.fail_host, P.ximg, P.rimg, acc_out); \
+    else hipLaunchKernelGGL((sweep_lines_kernel<B, A, false>), dim3(tiles), dim3(LINES_THREADS), 0, s, g, P.img, P.mimg, P.counter, P.fail, P.fail_host, P.ximg, P.rimg, acc_out); } while (0)
     if (P.b) { if (acc_out) ITS_LAUNCHLN(true, true); else ITS_LAUNCHLN(true, false); }
     else { if (acc_out) ITS_LAUNCHLN(false, true); else ITS_LAUNCHLN(false, false); }
 #undef ITS_LAUNCHLN

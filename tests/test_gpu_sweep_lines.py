@@ -23,7 +23,19 @@ GRIDS = {
     "lap3d_24x5": lambda: matgen.laplace3d_7pt(24, 5),       # fewer planes than a tile is deep
     "lap3d_12": lambda: matgen.laplace3d_7pt(12),
     "lap3d_64x20": lambda: matgen.laplace3d_7pt(64, 20),
+    # entries missing INSIDE the grid (every 7th strictly lower one dropped): the variant that skips by presence bits
+    "lap2d_72_holes": lambda: drop_lower_entries(*matgen.laplace2d_5pt(72)),
+    "lap3d_36_holes": lambda: drop_lower_entries(*matgen.laplace3d_7pt(36)),
 }
+
+
+def drop_lower_entries(rp, col, val, every=7):
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    lower = np.where(col < rows)[0]
+    keep = np.ones(len(col), bool); keep[lower[::every]] = False
+    rp2 = np.zeros(n + 1, rp.dtype); np.add.at(rp2, rows[keep] + 1, 1)
+    return np.cumsum(rp2).astype(rp.dtype), col[keep].copy(), val[keep].copy()
 
 
 def run_gs(rp, col, val, lines, trips=12, x0=None, b=None):
