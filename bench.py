@@ -58,7 +58,7 @@ def kernel_sources_hash():
     import hashlib
     hsh = hashlib.sha256()
     # the files that hold device code (host-side API changes do not invalidate a counter profile)
-    names = ("its_kernels.hip", "its_ell.hip", "its_ellg.hip", "its_ellm.hip", "its_panel.hip", "its_mgs.hip", "its_epilogue.h", "its_device.h", "its_kernels.h", "its_ap.h")
+    names = ("its_kernels.hip", "its_ell.hip", "its_ellg.hip", "its_ellm.hip", "its_lines.hip", "its_panel.hip", "its_mgs.hip", "its_epilogue.h", "its_device.h", "its_kernels.h", "its_ap.h")
     for f in sorted(os.path.join(ROOT, "iterative_solvers_amd", "csrc", nm) for nm in names):
         hsh.update(os.path.basename(f).encode()); hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]
@@ -418,6 +418,39 @@ def generic_spmv_entries(h, capi, rp, col, val, n, nnz, xd, yd, reps):
     return out
 
 
+def gauss_seidel_entries(capi, S, rp, col, val, n, nnz):
+    """Gauss-Seidel on the headline matrix, in the reference's natural order (methods/gauss_seidel.hpp:227, kernels.hpp:451-473:
+    the sweep of a stencil is one line-pipelined launch, csrc/its_lines.hip) and colour by colour (GS_ORDER = multicolor: the
+    same sweep on P A P^T).  A trip = b - U x, the sweep, the recorded residual.  Never `value`."""
+    out = {}
+    for key, order in (("natural_order", capi.GS_LEVEL), ("multicolour", capi.GS_MULTICOLOR)):
+        args = S.Args("gauss-seidel", S.LoopParams(max_iters=10**9, tol=0.0))
+        sol = S.Solver("gauss-seidel", device=0, gs_order=order)
+        t0 = time.time()
+        S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.ones(n))
+        setup = time.time() - t0
+        h = sol.handle
+        k = 0
+        for _ in range(3):
+            h.iterate(k); k += 1
+        h.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            h.iterate(k); k += 1
+        h.synchronize()
+        dt = (time.perf_counter() - t0) / 20
+        sw = h.sweep_info()
+        by = 2 * spmv_bytes(n, nnz) + 40 * n                     # SURVEY.md §8d, as for configs[3]: U + L, then A, + the vectors
+        out[key] = {"ms_per_trip": dt * 1e3, "trips_per_s": 1 / dt, "algorithmic_bytes_per_trip": by, "GBps_algorithmic": by / dt / 1e9,
+                    "frac_hbm_peak": by / dt / 1e9 / HBM_PEAK_GBS, "dependency_levels": sw["n_levels"],
+                    "sweep": (f"one launch pipelined over grid lines: {sw['workgroups']} tiles, lines of {sw['line_length']} rows in chunks of {sw['rows_per_chunk']}"
+                              if sw["workgroups"] else (f"{sol.n_colors} colours, a launch each" if sol.n_colors else "a launch per level")),
+                    "bound": "latency: the dependency chain of the sweep, not bandwidth" if order == capi.GS_LEVEL else "hbm",
+                    "setup_seconds": setup}
+        h.close()
+    return out
+
+
 def mixed_precision_entries(capi, S, device, rp, col, val, n, nnz, steps, reps):
     """SURVEY.md §8f.3 (the reference's USE_AP idea, config.mk:56-63), opt-in, never `value`: the SAME C2 system with its
     entries stored by magnitude — AP_THRESHOLD_1 = 2: the diagonal (6) in fp64, the off-diagonals (-1) in fp32 (ap[dp_sp])
@@ -711,6 +744,7 @@ def main():
     if rank == 0:
         if c2_single and not a.no_extra:
             # BASELINE.json configs[2] and configs[3] on the same GPU, as sub-objects (never `value`)
+            out["gauss_seidel"] = gauss_seidel_entries(capi, S, rp, col, val, n, nnz)
             del rp, col, val
             out["configs"] = other_configs(capi, matgen, S)
         print(json.dumps(out), flush=True)

@@ -191,46 +191,36 @@ static int pick_lanes_per_row(int n, int64_t nnz, int max_len)
 // SELL-64-sigma image, layout of CUDA_tests/helpers/utilities.cpp:183-361 (C = 64): rows sorted
 // by descending length inside windows of sigma rows, chunk c stored column-major at
 // chunk_ptr[c] + j*64 + r, padding = (col 0, val 0.0).
-static int build_sell(its_handle *h, CsrDev &A, int n, const int *rp, const int *col, const double *val)
+static int build_sell(its_handle *h, CsrDev &A, int n, const int *rp)
 {
+    // the order and the chunk lengths on the host cores in parallel (its_host::sell_order), chunk pointers in 64 bits, the
+    // col / val arrays filled on the device from the CRS arrays that are already there (launch_sell_fill): nothing of the
+    // size of the matrix is built or copied on the host any more
     const int C = 64;
     int sigma = 4096;
     bool sigma_fixed = false;
     if (const char *e = getenv("ITS_SELL_SIGMA")) { sigma = std::max(1, atoi(e)); sigma_fixed = true; }
     const int n_chunks = (n + C - 1) / C, n_pad = n_chunks * C;
     const int64_t nnz = n > 0 ? rp[n] : 0;
-    std::vector<int> order(n_pad);
-    auto len = [&](int r) { return r < n ? rp[r + 1] - rp[r] : 0; };
-    std::vector<int> cptr(n_chunks + 1), clen(n_chunks), perm(n_pad);
+    std::vector<int> order((size_t)n_pad), clen((size_t)n_chunks);
+    std::vector<long long> cptr((size_t)n_chunks + 1);
     int64_t tot = 0;
     // sigma grows (x8) while less than 60 % of the stored elements are real: power-law rows need a
     // wide sorting window before chunks of 64 rows have similar lengths
     for (;;) {
-        std::iota(order.begin(), order.end(), 0);
-        if (sigma > 1)
-            for (int i = 0; i < n_pad; i += sigma)
-                std::stable_sort(order.begin() + i, order.begin() + std::min(n_pad, i + sigma),
-                                 [&](int a, int b) { return len(a) > len(b); });
-        tot = 0;
-        for (int c = 0; c < n_chunks; ++c) {
-            int mx = 0;
-            for (int r = 0; r < C; ++r) mx = std::max(mx, len(order[c * C + r]));
-            clen[c] = mx;
-            tot += (int64_t)mx * C;
-        }
+        tot = its_host::sell_order(n, n_pad, rp, sigma, C, order.data(), clen.data());
         if (sigma_fixed || sigma >= n_pad || tot == 0 || (double)nnz / (double)tot >= 0.6) break;
         sigma = (int)std::min<int64_t>((int64_t)sigma * 8, n_pad);
     }
-    if (tot > INT32_MAX) FAIL(h, ITS_EUNSUPPORTED, "SELL image exceeds int32 offsets");
     tot = 0;
-    for (int c = 0; c < n_chunks; ++c) { cptr[c] = (int)tot; tot += (int64_t)clen[c] * C; }
-    cptr[n_chunks] = (int)tot;
+    for (int c = 0; c < n_chunks; ++c) { cptr[c] = tot; tot += (int64_t)clen[c] * C; }
+    cptr[n_chunks] = tot;
     // work-balanced static partition: groups of 4 chunks (one per wave) dealt to ITS_NPART workgroup
     // slots so that every slot gets about the same number of stored elements (+ a per-group constant)
     const int n_grp = (n_chunks + 3) / 4;
     std::vector<int> gstart(ITS_NPART + 1, n_grp);
     {
-        std::vector<int64_t> pre(n_grp + 1, 0);
+        std::vector<int64_t> pre((size_t)n_grp + 1, 0);
         for (int g = 0; g < n_grp; ++g) {
             int64_t wk = 16;
             for (int c = 4 * g; c < std::min(n_chunks, 4 * g + 4); ++c) wk += clen[c];
@@ -244,29 +234,21 @@ static int build_sell(its_handle *h, CsrDev &A, int n, const int *rp, const int 
         }
         gstart[0] = 0; gstart[ITS_NPART] = n_grp;
     }
-    std::vector<int> scol((size_t)tot, 0);
-    std::vector<double> sval((size_t)tot, 0.0);
-    for (int c = 0; c < n_chunks; ++c)
-        for (int r = 0; r < C; ++r) {
-            const int row = order[c * C + r];
-            perm[c * C + r] = row < n ? row : -1;
-            if (row >= n) continue;
-            for (int j = rp[row]; j < rp[row + 1]; ++j) {
-                const size_t idx = (size_t)cptr[c] + (size_t)(j - rp[row]) * C + r;
-                scol[idx] = col[j]; sval[idx] = val[j];
-            }
-        }
+    for (int i = 0; i < n_pad; ++i) if (order[i] >= n) order[i] = -1;     // (order becomes the image's row permutation)
     A.sell_chunks = n_chunks; A.sell_sigma = sigma; A.sell_elems = tot;
     if (dalloc(h, &A.sell_grp_start, gstart.size())) return ITS_EHIP;
     HIPCHK(h, hipMemcpy(A.sell_grp_start, gstart.data(), gstart.size() * sizeof(int), hipMemcpyHostToDevice));
-    if (dalloc(h, &A.sell_chunk_ptr, n_chunks + 1) || dalloc(h, &A.sell_chunk_len, n_chunks) ||
-        dalloc(h, &A.sell_perm, n_pad) || dalloc(h, &A.sell_col, (size_t)tot) || dalloc(h, &A.sell_val, (size_t)tot))
+    if (dalloc(h, &A.sell_chunk_ptr, (size_t)n_chunks + 1) || dalloc(h, &A.sell_chunk_len, (size_t)n_chunks) ||
+        dalloc(h, &A.sell_perm, (size_t)n_pad) || dalloc(h, &A.sell_col, (size_t)tot) || dalloc(h, &A.sell_val, (size_t)tot))
         return ITS_EHIP;
-    HIPCHK(h, hipMemcpy(A.sell_chunk_ptr, cptr.data(), (n_chunks + 1) * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(A.sell_chunk_len, clen.data(), n_chunks * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(A.sell_perm, perm.data(), n_pad * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(A.sell_col, scol.data(), (size_t)tot * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(A.sell_val, sval.data(), (size_t)tot * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(A.sell_chunk_ptr, cptr.data(), ((size_t)n_chunks + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(A.sell_chunk_len, clen.data(), (size_t)n_chunks * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(A.sell_perm, order.data(), (size_t)n_pad * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemsetAsync(A.sell_col, 0, (size_t)tot * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(A.sell_val, 0, (size_t)tot * sizeof(double), h->stream));
+    launch_sell_fill(A, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return ITS_OK;
 }
 
@@ -402,7 +384,7 @@ int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64
     }
     A.lanes_per_row = pick_lanes_per_row(n_rows, nnz, A.max_row_len);
     pt.lap("stream plans + statistics");
-    if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr, col, val); if (rc) return rc; pt.lap("SELL image"); }
+    if (format == ITS_FMT_SELL) { int rc = build_sell(h, A, n_rows, row_ptr); if (rc) return rc; pt.lap("SELL image"); }
     if (format == ITS_FMT_MIXED) {
         const size_t ne = (size_t)std::max<int64_t>(nnz, 1);
         std::vector<int> rpd((size_t)n_rows + 1), rps((size_t)n_rows + 1), rph((size_t)n_rows + 1), cd(ne), cs(ne), ch(ne);

@@ -239,6 +239,31 @@ void assemble_diag_upper(int n, const int *u_rp, const int *u_col, const double 
     }
 }
 
+// SELL-C-sigma: rows sorted by descending length inside windows of sigma rows (stable: ties keep row order, the layout of
+// CUDA_tests/helpers/utilities.cpp:183-361), then the longest row of every chunk of C; returns the stored elements
+int64_t sell_order(int n, int n_pad, const int *rp, int sigma, int C, int *order, int *clen)
+{
+    auto len = [&](int r) { return r < n ? rp[r + 1] - rp[r] : 0; };
+    const int n_win = sigma > 1 ? (n_pad + sigma - 1) / sigma : 0;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_pad; ++i) order[i] = i;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int w = 0; w < n_win; ++w) {
+        const int64_t lo = (int64_t)w * sigma, hi = std::min<int64_t>(n_pad, lo + sigma);
+        std::stable_sort(order + lo, order + hi, [&](int a, int b) { return len(a) > len(b); });
+    }
+    const int n_chunks = n_pad / C;
+    int64_t tot = 0;
+#pragma omp parallel for schedule(static) reduction(+ : tot)
+    for (int c = 0; c < n_chunks; ++c) {
+        int mx = 0;
+        for (int r = 0; r < C; ++r) mx = std::max(mx, len(order[(size_t)c * C + r]));
+        clen[c] = mx;
+        tot += (int64_t)mx * C;
+    }
+    return tot;
+}
+
 void split_by_magnitude(int n_rows, const int *rp, const int *col, const double *val, double thr,
                         int *rp_d, int *col_d, double *val_d, int *rp_s, int *col_s, float *val_s)
 {

@@ -27,6 +27,7 @@ void row_maxcol(int n_rows, const int *rp, const int *col, int limit, int *maxco
 
 // split by magnitude (ITS_FMT_MIXED): |val| >= thr -> (rp_d, col_d, val_d), else -> (rp_s, col_s, val_s as float);
 // row pointers n_rows + 1, the other outputs sized nnz; entry order inside a row kept
+int64_t sell_order(int n, int n_pad, const int *rp, int sigma, int C, int *order, int *clen);
 void split_by_magnitude(int n_rows, const int *rp, const int *col, const double *val, double thr,
                         int *rp_d, int *col_d, double *val_d, int *rp_s, int *col_s, float *val_s);
 

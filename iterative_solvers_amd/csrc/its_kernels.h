@@ -127,7 +127,8 @@ struct CsrDev {
     // SELL-64-sigma image
     int sell_chunks = 0, sell_sigma = 0;
     int64_t sell_elems = 0;
-    int *sell_chunk_ptr = nullptr, *sell_chunk_len = nullptr, *sell_col = nullptr, *sell_perm = nullptr;
+    long long *sell_chunk_ptr = nullptr;     // 64-bit: padding can take the stored elements past 2^31
+    int *sell_chunk_len = nullptr, *sell_col = nullptr, *sell_perm = nullptr;
     int *sell_grp_start = nullptr;           // [ITS_NPART + 1] chunk-group range of every workgroup slot (work-balanced)
     double *sell_val = nullptr;
 };
@@ -192,6 +193,7 @@ int ell_dict_forms_enabled();                            // option "spmv_ell_dic
 void launch_ell_build(const CsrDev &A, hipStream_t s, int row_base = 0);   // fills ell_val / ell_idx from the device CRS arrays
 int ell_tune(const char *name, int value);               // "spmv_ell", "spmv_ell_grid", "spmv_ell_nt", "spmv_ell_map"
 void launch_spmv_vector(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
+void launch_sell_fill(const CsrDev &A, hipStream_t s);   // sell_col / sell_val (zeroed) from the device CRS arrays, sell_perm, sell_chunk_ptr
 void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);
 void launch_spmv_mixed(const CsrDev &A, const SpmvArgs &a, int epilogue, hipStream_t s);   // EPI_STORE (+ dot), EPI_RESIDUAL
 // tiered sliced-ELL form of the mixed image (its_ellm.hip)

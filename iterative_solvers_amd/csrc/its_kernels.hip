@@ -1167,7 +1167,7 @@ constexpr int SELL_COOP = 512;   // chunks wider than this are shared by the fou
 
 template <int EPI, bool DOT>
 __global__ __launch_bounds__(ITS_BLOCK) void spmv_sell_kernel(
-    int n_rows, int n_chunks, const int *__restrict__ chunk_ptr, const int *__restrict__ chunk_len,
+    int n_rows, int n_chunks, const long long *__restrict__ chunk_ptr, const int *__restrict__ chunk_len,
     const int *__restrict__ scol, const double *__restrict__ sval, const int *__restrict__ perm,
     const int *__restrict__ grp_start, SpmvArgs a)
 {
@@ -1252,6 +1252,33 @@ __global__ __launch_bounds__(ITS_BLOCK) void spmv_sell_kernel(
             if (t == 0) a.part_max[blockIdx.x] = bm;
         }
     }
+}
+
+// The image's col / val arrays from the CRS arrays already on the device: a lane per stored row, entry j of row
+// perm[c * 64 + r] to chunk_ptr[c] + j * 64 + r (column-major inside the chunk, so the 64 lanes of a wave write 64
+// consecutive elements per step); the arrays were zeroed, which is the padding (col 0, val 0.0).
+__global__ __launch_bounds__(ITS_BLOCK) void sell_fill_kernel(
+    int n_rows, int n_chunks, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+    const long long *__restrict__ chunk_ptr, const int *__restrict__ perm, int *__restrict__ scol, double *__restrict__ sval)
+{
+    const int64_t i = (int64_t)blockIdx.x * ITS_BLOCK + threadIdx.x;
+    if (i >= (int64_t)n_chunks * 64) return;
+    const int row = perm[i];
+    if (row < 0 || row >= n_rows) return;
+    const int64_t base = chunk_ptr[i >> 6] + (i & 63);
+    const int lo = rp[row], hi = rp[row + 1];
+    for (int j = lo; j < hi; ++j) {
+        const int64_t idx = base + (int64_t)(j - lo) * 64;
+        scol[idx] = col[j]; sval[idx] = val[j];
+    }
+}
+
+void launch_sell_fill(const CsrDev &A, hipStream_t s)
+{
+    const int64_t rows = (int64_t)A.sell_chunks * 64;
+    if (rows == 0) return;
+    hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((rows + ITS_BLOCK - 1) / ITS_BLOCK)), dim3(ITS_BLOCK), 0, s, A.n_rows, A.sell_chunks,
+                       A.row_ptr, A.col, A.val, A.sell_chunk_ptr, A.sell_perm, A.sell_col, A.sell_val);
 }
 
 void launch_spmv_sell(const CsrDev &A, const SpmvArgs &a, int epi, hipStream_t s)

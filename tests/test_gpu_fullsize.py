@@ -97,6 +97,38 @@ def test_spmv_powerlaw_1m_bit_exact_and_sell(gpu_handle):
     orc.set_threads(1)
 
 
+def test_sell_image_beyond_2_31_stored_elements(gpu_handle, monkeypatch):
+    """A padded SELL-64 image of 2.4e9 stored elements (one row of 600 entries in every chunk of 64, sorting off): the
+    chunk pointers are 64-bit and the col / val arrays are filled on the device, so neither the int32 limit nor a host
+    copy of the image stands in the way (round 2: ITS_EUNSUPPORTED).  29 GB of device memory; against the oracle at 1e-12
+    of sum |a_ij x_j| (reordered summation)."""
+    monkeypatch.setenv("ITS_SELL_SIGMA", "1")
+    n_chunks, long_len = 1 << 16, 600
+    n = n_chunks * 64
+    lens = np.ones(n, np.int64); lens[::64] = long_len
+    rp = np.zeros(n + 1, np.int32); rp[1:] = np.cumsum(lens)
+    nnz = int(rp[-1])
+    rng = np.random.default_rng(12)
+    col = np.empty(nnz, np.int32)
+    rows = np.repeat(np.arange(n), lens)
+    first = np.repeat(rp[:-1].astype(np.int64), lens)
+    # row i: its diagonal, and for the long rows 599 further columns i + 1 + 7 k (mod n), ascending within the wrap
+    k = np.arange(nnz, dtype=np.int64) - first
+    col[:] = ((rows + np.where(k > 0, 1 + 7 * (k - 1), 0)) % n).astype(np.int32)
+    val = rng.uniform(-1, 1, nnz)
+    x = rng.uniform(-1, 1, n)
+    assert n_chunks * 64 * long_len > 2**31
+    orc.set_threads(min(16, orc.num_threads()))
+    ref = orc.spmv(rp, col, val, x)
+    absrow = orc.spmv(rp, col, np.abs(val), np.abs(x))
+    orc.set_threads(1)
+    gpu_handle.upload_crs(rp, col, val, capi.MAT_A, capi.FMT_SELL)
+    info = gpu_handle.plan_info(capi.MAT_A, capi.FMT_SELL)
+    assert 0 < info["sell_occupancy"] < nnz / 2.0**31
+    got = gpu_handle.spmv_host(x, n, capi.MAT_A, capi.FMT_SELL)
+    assert np.all(np.abs(got - ref) <= 1e-12 * absrow)
+
+
 def _envelope(want, alt, got, tol_rel=1e-10):
     """the 1e-10 bar, widened to 10x the oracle's own 1-vs-8-thread deviation (running maximum, 8 trips ahead)"""
     k = min(len(want), len(alt), len(got))
