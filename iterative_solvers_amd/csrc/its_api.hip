@@ -39,7 +39,7 @@ int build_panel_image(its_handle *h, CsrDev &A, const int *host_rp);    // its_p
 
 static void free_lines(its_handle *h)
 {
-    dfree(h->lines.img); dfree(h->lines.mimg); dfree(h->lines.rimg); dfree(h->lines.ximg); dfree(h->lines.sbase); dfree(h->lines.counter);
+    dfree(h->lines.img); dfree(h->lines.mimg); dfree(h->lines.rimg); dfree(h->lines.ximg); dfree(h->lines.xedge); dfree(h->lines.sbase); dfree(h->lines.tabs); dfree(h->lines.counter);
     h->lines = LinesPlan(); h->lines_ready = false;
 }
 
@@ -1089,22 +1089,22 @@ static int build_lines_plan(its_handle *h)
     P.n = n; P.a = (int)a; P.b = (int)b;
     P.ny = b ? (int)(b / a) : (int)(n / a);
     P.nz = b ? (int)(n / b) : 1;
-    P.ch = 4;
-    if (b) { P.ty = std::min(16, P.ny); P.tz = std::min(256 / P.ty, P.nz); }
-    else { P.ty = std::min(256, P.ny); P.tz = 1; }
-    P.nby = (P.ny + P.ty - 1) / P.ty; P.nbz = (P.nz + P.tz - 1) / P.tz;
+    lines_plan_geometry(P);
     // measured (tools/lines_probe.py, tools/sweep_lines_ab.py): faster than the level schedule from 16 x 16 rows to 256^3
     // (its_lines.hip), so taken wherever the matrix qualifies (option values 1 and 2 alike; 0 = level schedule)
     int *flags = nullptr;
-    auto give_up = [&]() { dfree(P.img); dfree(P.mimg); dfree(P.rimg); dfree(P.ximg); dfree(P.sbase); dfree(P.counter); dfree(flags); h->err.clear(); (void)hipGetLastError(); return ITS_OK; };
+    auto give_up = [&]() { dfree(P.img); dfree(P.mimg); dfree(P.rimg); dfree(P.ximg); dfree(P.xedge); dfree(P.sbase); dfree(P.tabs); dfree(P.counter); dfree(flags);
+                           h->err.clear(); (void)hipGetLastError(); return ITS_OK; };
     if (!h->D) return ITS_OK;
-    if (lines_image_doubles(P) > ((size_t)1 << 36)) return ITS_OK;
+    if (lines_image_doubles(P) > ((size_t)1 << 36) || (int64_t)P.nby * P.nbz * P.tslots > (int64_t)1 << 30) return ITS_OK;
     if (dalloc(h, &P.img, lines_image_doubles(P)) || dalloc(h, &P.mimg, lines_image_masks(P)) || dalloc(h, &P.rimg, 4 * lines_image_masks(P)) ||
-        dalloc(h, &P.ximg, 4 * lines_image_masks(P)) || dalloc(h, &P.counter, 8) || dalloc(h, &flags, 4)) return give_up();
-    if (hipMemsetAsync(flags, 0, 4 * sizeof(int), h->stream) != hipSuccess || hipMemsetAsync(P.counter, 0, 8 * sizeof(int), h->stream) != hipSuccess) return give_up();
-    std::vector<int> sbase((size_t)lines_steps(P) + 1);
-    lines_step_bases(P, sbase.data());
-    if (dalloc(h, &P.sbase, sbase.size()) || hipMemcpy(P.sbase, sbase.data(), sbase.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return give_up();
+        dalloc(h, &P.ximg, 4 * lines_image_masks(P)) || dalloc(h, &P.xedge, lines_edge_doubles(P)) || dalloc(h, &P.counter, 8) || dalloc(h, &flags, 4)) return give_up();
+    if (hipMemsetAsync(flags, 0, 4 * sizeof(int), h->stream) != hipSuccess || hipMemsetAsync(P.counter, 0, 8 * sizeof(int), h->stream) != hipSuccess ||
+        hipMemsetAsync(P.xedge, 0, lines_edge_doubles(P) * sizeof(double), h->stream) != hipSuccess) return give_up();
+    std::vector<int> sbase((size_t)P.nsteps + 1), tabs((size_t)4 * P.nsteps);
+    lines_step_tables(P, sbase.data(), tabs.data());
+    if (dalloc(h, &P.sbase, sbase.size()) || hipMemcpy(P.sbase, sbase.data(), sbase.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        dalloc(h, &P.tabs, tabs.size()) || hipMemcpy(P.tabs, tabs.data(), tabs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return give_up();
     launch_lines_build(P, L, h->D, flags, h->stream);
     int hflags[4] = {1, 0, 0, 0};
     if (hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return give_up();

@@ -291,18 +291,22 @@ void launch_sweep_ell_level(int n, int W, int p0, int p1, const int *rows, const
 // ---------------------------------------------------------------------------------------
 struct LinesPlan {
     int n = 0, a = 0, b = 0, ny = 0, nz = 0, ty = 0, tz = 0, nby = 0, nbz = 0, ch = 0;
+    int nsteps = 0, tslots = 0;                       // steps of a tile's sweep; slots (windows + a neutral one per step) of a tile
     double *img = nullptr;                            // operands in the order the sweep consumes them (its_lines.hip)
-    unsigned int *mimg = nullptr;                     // presence bits per chunk
+    unsigned int *mimg = nullptr;                     // presence bits per window
     double *rimg = nullptr, *ximg = nullptr;          // per sweep: right-hand side packed into, x produced in, the same order
+    double *xedge = nullptr;                          // the lines on the tiles' high edges, row-major: what neighbouring tiles poll
     bool masked = true;                               // rows with entries missing inside the grid: presence bits decide (its_lines.hip)
-    int *sbase = nullptr;                             // chunks of a tile before step S (the order's index, its_lines.hip)
+    int *sbase = nullptr, *tabs = nullptr;            // slots of a tile before step S; {active lanes, per-wave prefixes} of step S
     int *counter = nullptr, *fail = nullptr;          // tile counter; sticky "a poll gave up" flag (device)
     unsigned long long *fail_host = nullptr;          // the same, in pinned host memory (what the host checks)
 };
 size_t lines_image_doubles(const LinesPlan &P);
 size_t lines_image_masks(const LinesPlan &P);
 int lines_steps(const LinesPlan &P);
-void lines_step_bases(const LinesPlan &P, int *sbase);
+void lines_plan_geometry(LinesPlan &P);            // tile shape, steps and slots from a, b, ny, nz
+void lines_step_tables(const LinesPlan &P, int *sbase, int *tabs);
+size_t lines_edge_doubles(const LinesPlan &P);
 void launch_lines_build(const LinesPlan &P, const CsrDev &L, const double *D, int *flags, hipStream_t s);
 void launch_sweep_lines(const LinesPlan &P, double *x, const double *rhs, double *acc_out, hipStream_t s);
 
