@@ -1140,9 +1140,10 @@ static int sweep(its_handle *h, double *x, const double *rhs, int first_level = 
 {
     const CsrDev &L = h->mat[ITS_MAT_L];
     const bool dist = its_dist_active(h);
-    // stencil matrices in natural order: the whole sweep as one launch pipelined over grid lines (its_lines.hip); it presets
-    // x, so not for the in-place sweeps of the preconditioner (x == rhs)
-    if (h->lines_ready && h->sweep_lines && !h->lines_failed && !dist && first_level == 0 && x != rhs && h->D) {
+    // stencil matrices in natural order: the whole sweep as one launch pipelined over grid lines (its_lines.hip).  The
+    // right-hand side is packed before the sweep starts and x unpacked after it ends, so x may be rhs (the in-place sweeps
+    // of the preconditioner) and acc_out may be rhs
+    if (h->lines_ready && h->sweep_lines && !h->lines_failed && !dist && first_level == 0 && h->D) {
         launch_sweep_lines(h->lines, x, rhs, acc_out, h->stream);
         HIPCHK(h, hipGetLastError());
         return ITS_OK;

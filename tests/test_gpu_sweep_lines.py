@@ -111,8 +111,15 @@ def test_spltsv_entry_point_takes_the_line_sweep(gpu_handle):
         x = h.from_dev(px, n)
         assert h.sweep_info()["workgroups"] >= 1
         assert np.array_equal(x, orc.spltsv(Lp, Lc, Lv, D, rhs))
-        h.spltsv(pr, pr)                                     # in place (the preconditioner's form): the level schedule
+        h.spltsv(pr, pr)                                     # in place (the preconditioner's form): packed before, unpacked after
         assert np.array_equal(h.from_dev(pr, n), x)
+        h.set_option("sweep_lines", 0)
+        pr2 = h.to_dev(rhs)
+        try:
+            h.spltsv(pr2, pr2)                               # the level schedule, in place
+            assert np.array_equal(h.from_dev(pr2, n), x)
+        finally:
+            h.dev_free(pr2); h.set_option("sweep_lines", 1)
     finally:
         h.dev_free(px); h.dev_free(pr)
 
