@@ -23,6 +23,10 @@ GRIDS = {
     "lap3d_24x5": lambda: matgen.laplace3d_7pt(24, 5),       # fewer planes than a tile is deep
     "lap3d_12": lambda: matgen.laplace3d_7pt(12),
     "lap3d_64x20": lambda: matgen.laplace3d_7pt(64, 20),
+    # lines much longer than the grid is wide (a lane walks thousands of rows; 2-D: 20 lines, 3-D: 7 x 5 lines)
+    "rect2d_20x2052": lambda: matgen._stencil_crs((1, 20, 2052), [(0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0)], [-1.0, -1.0, 4.0, -1.0, -1.0]),
+    "rect3d_5x7x1028": lambda: matgen._stencil_crs((5, 7, 1028), [(-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0)],
+                                                   [-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0]),
     # entries missing INSIDE the grid (every 7th strictly lower one dropped): the variant that skips by presence bits
     "lap2d_72_holes": lambda: drop_lower_entries(*matgen.laplace2d_5pt(72)),
     "lap3d_36_holes": lambda: drop_lower_entries(*matgen.laplace3d_7pt(36)),
