@@ -244,8 +244,8 @@ int its_gs_info(its_handle *h, int *prefix_ready, int64_t *nnz_du, char *kernel,
 /* after its_solver_setup with crs_L: how the forward substitution of kernels.hpp:451-473 is scheduled.  n_levels = launches
  * (dependency levels, or colours) of the level schedule.  lines_workgroups > 0: the sweep runs instead as ONE launch
  * pipelined over grid lines (csrc/its_lines.hip; stencil matrices whose strictly lower offsets are {-1, -a[, -b]}; option
- * "sweep_lines": 0 never, 1 (default) where it is faster — grids of one or two tiles of 256 lines — 2 wherever the matrix
- * qualifies), bit-identical to the level schedule; line_length = a, rows_per_chunk = rows a lane advances per step */
+ * "sweep_lines": 0 never, 1 (default) wherever the matrix qualifies), bit-identical to the level schedule, x may be rhs;
+ * line_length = a, rows_per_chunk = rows a lane advances per step */
 int its_sweep_info(its_handle *h, int *lines_workgroups, int *line_length, int *rows_per_chunk, int *n_levels);
 
 /* ---- Gauss-Seidel ordering helpers (host only, no GPU needed) -------------------------

@@ -611,7 +611,7 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         return ITS_OK;
     }
     if (!strcmp(name, "sweep_lines")) {
-        if (value < 0 || value > 2) FAIL(h, ITS_EINVAL, "sweep_lines: 0 (level schedule), 1 (line-pipelined sweep where it pays: grids of one or two tiles) or 2 (wherever the matrix qualifies)");
+        if (value < 0 || value > 2) FAIL(h, ITS_EINVAL, "sweep_lines: 0 (level schedule) or 1 (line-pipelined sweep wherever the matrix qualifies; 2 means the same)");
         h->sweep_lines = value;
         return ITS_OK;
     }
