@@ -1083,7 +1083,7 @@ static int build_lines_plan(its_handle *h)
     std::sort(dict, dict + L.n_off);                          // most negative first
     if (dict[L.n_off - 1] != -1) return ITS_OK;
     const int64_t a = -(int64_t)dict[L.n_off - 2], b = L.n_off == 3 ? -(int64_t)dict[0] : 0;
-    if (a < 4 || (a & 3) || n % a) return ITS_OK;
+    if (a < 4 || (a & 3) || n % a || a > ((int64_t)1 << 22)) return ITS_OK;     // (lines of more than 4 M rows: the step tables would be the size of the matrix)
     if (b && (b <= a || b % a || n % b)) return ITS_OK;
     LinesPlan P;
     P.n = n; P.a = (int)a; P.b = (int)b;

@@ -558,17 +558,37 @@ __global__ __launch_bounds__(LINES_THREADS) void sweep_lines_kernel(
 }
 
 // ---- host side
+// lanes of wave w with rho <= r, r = -1 .. rho_max (index r + 1): what the step tables are made of
+static void lines_rho_prefix(bool two_d, std::vector<int> (&cum)[LINES_WG / ITS_WAVE])
+{
+    const int rmax = ln_rho_max(two_d);
+    for (int w = 0; w < LINES_WG / ITS_WAVE; ++w) {
+        cum[w].assign((size_t)rmax + 2, 0);
+        for (int l = 0; l < ITS_WAVE; ++l) cum[w][(size_t)ln_rho(w * ITS_WAVE + l, two_d) + 1] += 1;
+        for (int r = 0; r <= rmax; ++r) cum[w][(size_t)r + 1] += cum[w][(size_t)r];
+    }
+}
+// lanes of a wave that have a window at step S: those with 4 S - a < rho < 4 S + 4
+static int lines_active(const std::vector<int> &cum, int rmax, int a, int64_t S)
+{
+    int64_t lo = 4 * S - a + 1, hi = 4 * S + 3;
+    if (lo < 0) lo = 0;
+    if (hi > rmax) hi = rmax;
+    return hi >= lo ? cum[(size_t)hi + 1] - cum[(size_t)lo] : 0;
+}
 void lines_plan_geometry(LinesPlan &P)
 {
     const bool two_d = P.b == 0;
     P.ty = two_d ? 256 : 16; P.tz = two_d ? 1 : 16; P.ch = LN_CH;
     P.nby = (P.ny + P.ty - 1) / P.ty; P.nbz = (P.nz + P.tz - 1) / P.tz;
     P.nsteps = (P.a - 1 + ln_rho_max(two_d)) / LN_CH + 1;
+    // every lane has a window at (a + 3) / 4 or one more steps, and every step has one neutral slot
+    std::vector<int> cum[LINES_WG / ITS_WAVE];
+    lines_rho_prefix(two_d, cum);
     int64_t slots = 0;
     for (int S = 0; S < P.nsteps; ++S) {
-        int cnt = 0;
-        for (int t = 0; t < LINES_WG; ++t) { const int w0 = 4 * S - ln_rho(t, two_d); cnt += w0 > -LN_CH && w0 < P.a; }
-        slots += cnt + 1;
+        for (int w = 0; w < LINES_WG / ITS_WAVE; ++w) slots += lines_active(cum[w], ln_rho_max(two_d), P.a, S);
+        slots += 1;
     }
     P.tslots = (int)slots;
 }
@@ -576,10 +596,12 @@ void lines_plan_geometry(LinesPlan &P)
 void lines_step_tables(const LinesPlan &P, int *sbase, int *tabs)
 {
     const bool two_d = P.b == 0;
+    std::vector<int> cum[LINES_WG / ITS_WAVE];
+    lines_rho_prefix(two_d, cum);
     int base = 0;
     for (int S = 0; S < P.nsteps; ++S) {
-        int per_wave[LINES_WG / ITS_WAVE] = {0, 0, 0, 0};
-        for (int t = 0; t < LINES_WG; ++t) { const int w0 = 4 * S - ln_rho(t, two_d); per_wave[t / ITS_WAVE] += w0 > -LN_CH && w0 < P.a; }
+        int per_wave[LINES_WG / ITS_WAVE];
+        for (int w = 0; w < LINES_WG / ITS_WAVE; ++w) per_wave[w] = lines_active(cum[w], ln_rho_max(two_d), P.a, S);
         const int cnt = per_wave[0] + per_wave[1] + per_wave[2] + per_wave[3];
         sbase[S] = base;
         tabs[4 * S] = cnt; tabs[4 * S + 1] = per_wave[0]; tabs[4 * S + 2] = per_wave[0] + per_wave[1]; tabs[4 * S + 3] = per_wave[0] + per_wave[1] + per_wave[2];
