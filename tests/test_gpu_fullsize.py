@@ -73,6 +73,37 @@ def test_cg_256cubed_history(lap256):
     assert np.all(np.abs(g - w) <= bound), (np.abs(g - w) / w, bound / w)
 
 
+def test_gauss_seidel_natural_order_256cubed_iterate(lap256):
+    """The reference's default sweep order at configs[1]'s size: 256 tiles of the line-pipelined sweep (csrc/its_lines.hip)
+    resident at once, every tile edge polled across XCDs.  Three trips from a random start with a random right-hand side:
+    the iterate == the oracle's sequential sweeps (kernels.hpp:451-473, gauss_seidel.hpp:227) bit for bit, and == the level
+    schedule's; recorded norms 1e-10."""
+    rp, col, val = lap256
+    n = len(rp) - 1
+    rng = np.random.default_rng(21)
+    b = rng.uniform(-1, 1, n); x0 = rng.uniform(-1, 1, n)
+    trips = 3
+    orc.set_threads(1)
+    ref = orc.solve(rp, col, val, b, x0, orc.GAUSS_SEIDEL, max_iters=trips, tol=1e-300)
+    got = {}
+    for lines in (1, 0):
+        args = S.Args("gauss-seidel", S.LoopParams(max_iters=trips, tol=1e-300), S.Flags(), "", "none")
+        sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_LEVEL)
+        try:
+            sol.handle.set_option("sweep_lines", lines)
+            S.preprocessing_crs(args, sol, rp, col, val, b, x0)
+            info = sol.handle.sweep_info()
+            assert (info["workgroups"] == 256) == bool(lines)
+            S.solve(args, sol)
+            got[lines] = (args.normed_residuals[:args.loop_params.residual_count].copy(), sol.x_star.copy())
+        finally:
+            sol.handle.close()
+    assert np.array_equal(got[1][1], ref["x_star"])
+    assert np.array_equal(got[1][1], got[0][1]) and np.array_equal(got[1][0], got[0][0])
+    k = min(len(got[1][0]), len(ref["history"]))
+    assert k >= trips and np.max(np.abs(got[1][0][:k] - ref["history"][:k])) <= 1e-10 * ref["r0_two"]
+
+
 def test_spmv_27pt_128cubed_bit_exact(gpu_handle):
     rp, col, val = matgen.convdiff3d_27pt(128)
     n = len(rp) - 1
