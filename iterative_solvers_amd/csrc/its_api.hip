@@ -615,6 +615,13 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->sweep_lines = value;
         return ITS_OK;
     }
+    if (!strcmp(name, "sweep_lines_fault")) {
+        // test hook: the first tile of the next line sweeps keeps its edge lines to itself, so its neighbours' polls run
+        // into their time limit — what a hung or time-sliced GPU looks like to the sweep (tests/test_gpu_sweep_lines.py)
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_lines_fault: 0 or 1");
+        h->lines.mute_first_tile = value != 0;
+        return ITS_OK;
+    }
     if (!strcmp(name, "sweep_run")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_run: 0 or 1");
         h->sweep_run = value;
@@ -1115,6 +1122,7 @@ static int build_lines_plan(its_handle *h)
     P.fail = P.counter + 4;
     P.fail_host = reinterpret_cast<unsigned long long *>(h->pinned + PIN_LINES);
     *reinterpret_cast<volatile unsigned long long *>(P.fail_host) = 0ull;
+    P.mute_first_tile = h->lines.mute_first_tile;
     h->lines = P; h->lines_ready = true; h->lines_failed = false;
     if (getenv("ITS_DEBUG_LINES"))
         fprintf(stderr, "its: line-pipelined sweep: lines of %d rows, %d x %d lines, tiles of %d x %d lines (%d workgroups), chunks of %d rows\n",

@@ -297,6 +297,7 @@ struct LinesPlan {
     double *rimg = nullptr, *ximg = nullptr;          // per sweep: right-hand side packed into, x produced in, the same order
     double *xedge = nullptr;                          // the lines on the tiles' high edges, row-major: what neighbouring tiles poll
     bool masked = true;                               // rows with entries missing inside the grid: presence bits decide (its_lines.hip)
+    bool mute_first_tile = false;                     // test hook (option "sweep_lines_fault"): tile 0 publishes nothing
     int *sbase = nullptr, *tabs = nullptr;            // slots of a tile before step S; {active lanes, per-wave prefixes} of step S
     int *counter = nullptr, *fail = nullptr;          // tile counter; sticky "a poll gave up" flag (device)
     unsigned long long *fail_host = nullptr;          // the same, in pinned host memory (what the host checks)

@@ -48,7 +48,7 @@ constexpr int LN_PAD = 4;           // rows of padding on both ends of a line of
 constexpr int LINES_THREADS = LINES_WG + ITS_WAVE;   // four waves of lanes that own lines + the edge wave
 typedef double lines_v2d __attribute__((ext_vector_type(2)));
 typedef double lines_v2du __attribute__((ext_vector_type(2), aligned(8)));    // row-order side: a window starts at any row
-struct LinesGeom { int n, a, b, ny, nz, nby, nbz, nsteps, tslots, start; const int *sbase; const int4 *tabs; };
+struct LinesGeom { int n, a, b, ny, nz, nby, nbz, nsteps, tslots, start, mute; const int *sbase; const int4 *tabs; };
 
 // ---- Geometry.  Lane t of a tile: 3-D (ty, tz) = (t & 15, t >> 4) of 16 x 16 lines, 2-D ty = t of 256 x 1.
 // rho(t) = rows the lane is behind lane 0: one per line inside a wave, and from wave to wave 4 more than the last lane
@@ -382,8 +382,9 @@ __global__ __launch_bounds__(LINES_THREADS) void sweep_lines_kernel(
         const int ia = (TWO_D ? t > 0 : ty > 0) ? t - 1 : LINES_WG + tz;         // line y - 1 when it is not the lane below: last wave's, or fetched by the edge wave
         const int ib = tz > 0 ? t - 16 : LINES_WG + 16 + ty;                      // line z - 1 likewise
         const bool z_in_wave = !TWO_D && (t & 48) != 0;
-        const bool pub_a = valid && ty == TY - 1 && y + 1 < g.ny;
-        const bool pub_b = HAVE_B && valid && tz == TZ - 1 && z + 1 < g.nz;
+        const bool mute = g.mute != 0 && tile == 0;                            // (test hook: see its_set_option "sweep_lines_fault")
+        const bool pub_a = valid && ty == TY - 1 && y + 1 < g.ny && !mute;
+        const bool pub_b = HAVE_B && valid && tz == TZ - 1 && z + 1 < g.nz && !mute;
         double *xe_a = xedge + ln_edge_off(g, tile, 0, TWO_D ? 0 : tz);
         double *xe_b = xedge + ln_edge_off(g, tile, 1, ty);
         double xl = 0.0;                                 // the line's newest value
@@ -616,6 +617,7 @@ static LinesGeom lines_geom(const LinesPlan &P)
     g.sbase = P.sbase; g.tabs = reinterpret_cast<const int4 *>(P.tabs);
     static const int start = getenv("ITS_LINES_START") ? atoi(getenv("ITS_LINES_START")) : 6;
     g.start = start < 0 ? 0 : start;
+    g.mute = P.mute_first_tile ? 1 : 0;
     return g;
 }
 int lines_steps(const LinesPlan &P) { return P.nsteps; }

@@ -142,3 +142,26 @@ def test_default_takes_the_line_sweep_wherever_the_matrix_qualifies():
             assert (info["workgroups"] > 0) == want and info["n_levels"] > 1
         finally:
             sol.handle.close()
+
+
+def test_a_sweep_that_cannot_finish_says_so_and_the_handle_falls_back():
+    """Option "sweep_lines_fault" (test hook): the first tile keeps its edge lines to itself, the next tile's polls run into
+    their time limit (50 ms) — what a hung or time-sliced neighbour looks like.  The trip must return ITS_ESTATE with a
+    message instead of an iterate, and the handle must run its next sweeps on the level schedule."""
+    rp, col, val = matgen.laplace2d_5pt(520)                 # three tiles
+    n = len(rp) - 1
+    args = S.Args("gauss-seidel", S.LoopParams(max_iters=3, tol=1e-300), S.Flags(), "", "none")
+    sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_LEVEL)
+    try:
+        S.preprocessing_crs(args, sol, rp, col, val, np.ones(n), np.zeros(n))
+        h = sol.handle
+        assert h.sweep_info()["workgroups"] == 3
+        h.iterate(0)                                         # a good trip first
+        h.set_option("sweep_lines_fault", 1)
+        with pytest.raises(capi.ItsError, match="gave up waiting"):
+            h.iterate(1)
+        h.set_option("sweep_lines_fault", 0)
+        assert h.sweep_info()["workgroups"] == 0             # from here on: the level schedule
+        h.iterate(2)                                         # runs (on an iterate that is no longer the reference's)
+    finally:
+        sol.handle.close()
