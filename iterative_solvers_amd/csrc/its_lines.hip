@@ -403,6 +403,10 @@ __global__ __launch_bounds__(LINES_THREADS) void sweep_lines_kernel(
         LN_ISSUE(0) LN_ISSUE(1) LN_ISSUE(2)
         if constexpr (K == 5) LN_ISSUE(3)
         static_assert(LN_K == 5, "the step loop is unrolled by hand");
+        // what step 0 reads as "the window the wave below finished last": nothing has been written there yet, and LDS keeps
+        // whatever the last kernel on this CU left — a NaN there would turn 0.0 * x into NaN in front of a line's first row
+        // (found as a poll that never ended: the NaN was a previous sweep's pending pattern, stored as a value)
+        _Pragma("unroll") for (int u = 0; u < LN_CH; ++u) s_c[1][t][u] = 0.0;
         ln_barrier();                                    // (the edge wave has written the rows of step 0)
         int buf = 0;
 #define LN_STEP(I)                                                                                                \
