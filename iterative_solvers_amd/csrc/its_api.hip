@@ -88,6 +88,24 @@ static int size_pinned(its_handle *h, int m)
     return ITS_OK;
 }
 
+// ITS_DEBUG_POISON_LDS=1 (test aid): every compute entry point first fills the LDS of all CUs with a NaN pattern, so that
+// a kernel reading LDS it has not written shows up as a wrong result instead of depending on what ran before it
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned long long *sink)
+{
+    __shared__ unsigned long long s_p[8192];                   // 64 KB: two workgroups per CU
+    for (int i = threadIdx.x; i < 8192; i += 256) s_p[i] = 0x7ff8dead0badf11dull;     // (the line sweep's pending pattern, its_lines.hip)
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 2000) { }                     // 20 us: long enough for the launch to cover every CU
+    if (sink && s_p[(threadIdx.x * 37) & 8191] != 0x7ff8dead0badf11dull) *sink = 1;
+}
+static void launch_lines_poison_lds(hipStream_t s) { hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), 0, s, (unsigned long long *)nullptr); }
+static void debug_poison_lds(its_handle *h)
+{
+    static const bool on = getenv("ITS_DEBUG_POISON_LDS") && atoi(getenv("ITS_DEBUG_POISON_LDS")) != 0;
+    if (on && h) launch_lines_poison_lds(h->stream);
+}
+
 extern "C" int its_device_count(void)
 {
     int ndev = 0;
@@ -622,6 +640,13 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         h->lines.mute_first_tile = value != 0;
         return ITS_OK;
     }
+    if (!strcmp(name, "debug_poison_lds")) {
+        // test hook: fills the LDS of every CU with a NaN pattern (what a kernel finds there is whatever the last one left)
+        launch_lines_poison_lds(h->stream);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return ITS_OK;
+    }
     if (!strcmp(name, "sweep_run")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_run: 0 or 1");
         h->sweep_run = value;
@@ -798,6 +823,7 @@ extern "C" int its_upload_vectors(its_handle *h, const double *D, const double *
 
 extern "C" int its_init_residual(its_handle *h, double *r0_inf, double *r0_two)
 {
+    debug_poison_lds(h);
     if (!h) return ITS_EINVAL;
     if (!h->x_a) FAIL(h, ITS_ESTATE, "its_upload_vectors first");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1717,6 +1743,7 @@ static int check_ready(its_handle *h)
 
 extern "C" int its_iterate(its_handle *h, int iter_count, double *residual_norm)
 {
+    debug_poison_lds(h);
     int rc = check_ready(h);
     if (rc) return rc;
     if (!residual_norm) return ITS_EINVAL;
@@ -1747,6 +1774,7 @@ extern "C" int its_iterate(its_handle *h, int iter_count, double *residual_norm)
 
 extern "C" int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double *residuals)
 {
+    debug_poison_lds(h);
     int rc = check_ready(h);
     if (rc) return rc;
     if (n_trips < 1 || !residuals) return ITS_EINVAL;
@@ -1803,6 +1831,7 @@ extern "C" int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double
 
 extern "C" int its_gmres_restart(its_handle *h, int iter_count)
 {
+    debug_poison_lds(h);
     int rc = check_ready(h);
     if (rc) return rc;
     if (h->solver != ITS_GMRES) FAIL(h, ITS_ESTATE, "not a GMRES handle");
@@ -1857,6 +1886,7 @@ extern "C" int its_download_x(its_handle *h, double *x_star, int n, int iter_cou
 
 extern "C" int its_final_residual(its_handle *h, double *residual_norm)
 {
+    debug_poison_lds(h);
     int rc = check_ready(h);
     if (rc) return rc;
     if (!residual_norm) return ITS_EINVAL;
@@ -1887,6 +1917,7 @@ extern "C" int its_final_residual(its_handle *h, double *residual_norm)
 // ---------------------------------------------------------------------------------------
 extern "C" int its_spmv(its_handle *h, int which, const double *x, double *y, int where, int format)
 {
+    debug_poison_lds(h);
     if (!h || which < 0 || which > 2 || !x || !y) return ITS_EINVAL;
     if (!h->have[which]) FAIL(h, ITS_ESTATE, "matrix not uploaded");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1978,6 +2009,7 @@ static int scalar_out(its_handle *h, double *out)
 
 extern "C" int its_dot(its_handle *h, const double *a, const double *b, int64_t n, double *out)
 {
+    debug_poison_lds(h);
     if (!h || !a || !b || !out || n < 0) return ITS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     launch_dot_partials(a, b, n, h->part[2], h->stream);
@@ -2007,6 +2039,7 @@ extern "C" int its_dot_noalloc(its_handle *h, const double *a_dev, const double 
 
 extern "C" int its_nrm2(its_handle *h, const double *v, int64_t n, double *out)
 {
+    debug_poison_lds(h);
     if (!h || !v || !out || n < 0) return ITS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     launch_dot_partials(v, v, n, h->part[2], h->stream);
@@ -2016,6 +2049,7 @@ extern "C" int its_nrm2(its_handle *h, const double *v, int64_t n, double *out)
 
 extern "C" int its_norm_inf(its_handle *h, const double *v, int64_t n, double *out)
 {
+    debug_poison_lds(h);
     if (!h || !v || !out || n < 0) return ITS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     launch_absmax_partials(v, n, h->part[2], h->stream);
@@ -2025,6 +2059,7 @@ extern "C" int its_norm_inf(its_handle *h, const double *v, int64_t n, double *o
 
 extern "C" int its_axpby(its_handle *h, double *out, const double *a, const double *b, int64_t n, double s)
 {
+    debug_poison_lds(h);
     if (!h || !out || !a || !b || n < 0) return ITS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     launch_axpby(out, a, b, n, s, h->stream);
@@ -2035,6 +2070,7 @@ extern "C" int its_axpby(its_handle *h, double *out, const double *a, const doub
 
 extern "C" int its_scale(its_handle *h, double *out, const double *v, double s, int64_t n)
 {
+    debug_poison_lds(h);
     if (!h || !out || !v || n < 0) return ITS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     launch_scale(out, v, s, n, h->stream);
@@ -2045,6 +2081,7 @@ extern "C" int its_scale(its_handle *h, double *out, const double *v, double s, 
 
 extern "C" int its_spltsv(its_handle *h, double *x_dev, const double *rhs_dev)
 {
+    debug_poison_lds(h);
     if (!h || !x_dev || !rhs_dev) return ITS_EINVAL;
     if (!h->have[ITS_MAT_L] || !h->D) FAIL(h, ITS_ESTATE, "needs crs_L and D");
     HIPCHK(h, hipSetDevice(h->device));

@@ -165,3 +165,27 @@ def test_a_sweep_that_cannot_finish_says_so_and_the_handle_falls_back():
         h.iterate(2)                                         # runs (on an iterate that is no longer the reference's)
     finally:
         sol.handle.close()
+
+
+def test_sweep_does_not_read_lds_it_has_not_written(gpu_handle):
+    """LDS keeps what the last kernel on a CU left.  With every CU's LDS full of the sweep's own pending pattern (a NaN;
+    test hook "debug_poison_lds") the line sweep must still produce the oracle's iterate: the rows in front of a line's
+    first row are 0.0 * (what the wave below finished last), and at step 0 nothing has finished yet."""
+    for gen in (lambda: matgen.laplace3d_7pt(40), lambda: matgen.laplace2d_5pt(520)):
+        rp, col, val = gen()
+        n = len(rp) - 1
+        b = np.random.default_rng(2).uniform(-1, 1, n)
+        args = S.Args("gauss-seidel", S.LoopParams(max_iters=4, tol=1e-300), S.Flags(), "", "none")
+        sol = S.Solver("gauss-seidel", device=0, gs_order=capi.GS_LEVEL)
+        try:
+            S.preprocessing_crs(args, sol, rp, col, val, b, np.zeros(n))
+            assert sol.handle.sweep_info()["workgroups"] > 1
+            for it in range(4):
+                sol.handle.set_option("debug_poison_lds", 1)
+                sol.handle.iterate(it)
+            x = sol.handle.download_x(n, 4)
+        finally:
+            sol.handle.close()
+        orc.set_threads(1)
+        ref = orc.solve(rp, col, val, b, np.zeros(n), orc.GAUSS_SEIDEL, max_iters=4, tol=1e-300)
+        assert np.array_equal(x, ref["x_star"])
