@@ -159,7 +159,12 @@ constexpr size_t PIN_REGIONS = 16;        // first index of the restart-length-s
 template <class T> static inline int dalloc(its_handle *h, T **p, size_t count)
 {
     void *q = nullptr;
-    HIPCHK(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T) + 256));
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + 256;
+    HIPCHK(h, hipMalloc(&q, bytes));
+    // ITS_DEBUG_POISON_MALLOC=1 (test aid): every allocation starts as all-ones (NaN as a double, -1 as an index) instead of
+    // whatever the allocator hands out — fresh memory is zero in a new process and something else later
+    static const bool poison = getenv("ITS_DEBUG_POISON_MALLOC") && atoi(getenv("ITS_DEBUG_POISON_MALLOC")) != 0;
+    if (poison) { HIPCHK(h, hipMemset(q, 0xFF, bytes)); HIPCHK(h, hipDeviceSynchronize()); }     // (the fill must not overtake what the caller queues next)
     *p = (T *)q;
     return ITS_OK;
 }
