@@ -108,6 +108,29 @@ __device__ __forceinline__ void ln_where(const LinesGeom &g, int64_t bid, int t,
 __device__ __forceinline__ size_t ln_edge_off(const LinesGeom &g, int tile, int side, int idx)
 { return (((size_t)tile * 2 + side) * 16 + idx) * (size_t)(g.a + 2 * LN_PAD) + LN_PAD; }
 
+// Row-order side of the two passes below.  A lane's LN_G windows are 16 consecutive rows of its line, and the lines of a
+// tile lie a whole line apart: lane by lane every 16-byte access would touch a cache line of its own.  So the workgroup
+// moves the tile's 256 x 16 rows through LDS: piece p = (line p / 8, rows 2 (p % 8) ..+1), eight consecutive threads on the
+// 128 consecutive bytes of one line.
+constexpr int LN_ROWS = LN_G * LN_CH;                         // rows of a line per workgroup
+struct LnPiece { int line, r; bool ok0, ok1; int64_t at; };
+__device__ __forceinline__ LnPiece ln_piece(const LinesGeom &g, int tile, int S0, int p)
+{
+    const bool two_d = g.b == 0;
+    LnPiece q;
+    q.line = p / (LN_ROWS / 2);
+    const int part = p % (LN_ROWS / 2);
+    const int by = tile % g.nby, bz = tile / g.nby;
+    const int ty = two_d ? q.line : (q.line & 15), tz = two_d ? 0 : (q.line >> 4);
+    const int y = by * (two_d ? 256 : 16) + ty, z = bz * (two_d ? 1 : 16) + tz;
+    q.r = 4 * S0 - ln_rho(q.line, two_d) + 2 * part;
+    const bool lv = y < g.ny && z < g.nz;
+    q.ok0 = lv && q.r >= 0 && q.r < g.a;
+    q.ok1 = lv && q.r + 1 >= 0 && q.r + 1 < g.a;
+    q.at = ((int64_t)z * g.ny + y) * g.a + q.r;
+    return q;
+}
+
 // The (<= 3) entries of each row into fixed slots — offset -b, -a, -1, which is ascending column order — flags[0] |= 1 when
 // a row is not of that form, |= 2 when a row lacks an entry where the grid has the neighbour (the sweep must then skip by
 // presence bits).  Rows outside the line or the grid, and the neutral slot: no entries, diagonal 1.
@@ -180,22 +203,25 @@ __global__ __launch_bounds__(LINES_WG) void lines_pack_kernel(
     LnWhere ws[LN_G];
     ln_where(g, blockIdx.x, t, ws, s_w);
     if (blockIdx.x == 0 && t == 0) *counter = 0;
-    double r[LN_G][LN_CH];
+    __shared__ double s_t[LINES_WG][LN_ROWS + 1];
+    {
+        const int tile = ws[0].tile, S0 = ws[0].S;
 #pragma unroll
-    for (int j = 0; j < LN_G; ++j) {
-        const LnWhere &w = ws[j];
-        const int64_t line = ((int64_t)w.z * g.ny + w.y) * g.a;
-        if (w.active && w.line_valid && w.w0 >= 0 && w.w0 + LN_CH <= g.a) {    // (plain loads: a lane's windows share cache lines)
-            const lines_v2du a01 = *reinterpret_cast<const lines_v2du *>(rhs + line + w.w0), a23 = *reinterpret_cast<const lines_v2du *>(rhs + line + w.w0 + 2);
-            r[j][0] = a01.x; r[j][1] = a01.y; r[j][2] = a23.x; r[j][3] = a23.y;
-        } else {
-#pragma unroll
-            for (int u = 0; u < LN_CH; ++u) {
-                const int p = w.w0 + u;
-                r[j][u] = (w.active && w.line_valid && p >= 0 && p < g.a) ? rhs[line + p] : 0.0;
-            }
+        for (int k = 0; k < LN_ROWS / 2; ++k) {
+            const LnPiece q = ln_piece(g, tile, S0, t + LINES_WG * k);
+            double v0 = 0.0, v1 = 0.0;
+            if (q.ok0 && q.ok1) { const lines_v2du a = *reinterpret_cast<const lines_v2du *>(rhs + q.at); v0 = a.x; v1 = a.y; }
+            else { if (q.ok0) v0 = rhs[q.at]; if (q.ok1) v1 = rhs[q.at + 1]; }
+            const int c = 2 * ((t + LINES_WG * k) % (LN_ROWS / 2));
+            s_t[q.line][c] = v0; s_t[q.line][c + 1] = v1;
         }
     }
+    __syncthreads();
+    double r[LN_G][LN_CH];
+#pragma unroll
+    for (int j = 0; j < LN_G; ++j)
+#pragma unroll
+        for (int u = 0; u < LN_CH; ++u) r[j][u] = s_t[t][j * LN_CH + u];
 #pragma unroll
     for (int j = 0; j < LN_G; ++j) {
         const LnWhere &w = ws[j];
@@ -241,21 +267,21 @@ __global__ __launch_bounds__(LINES_WG) void lines_unpack_kernel(LinesGeom g, con
         r01[j] = __builtin_nontemporal_load(reinterpret_cast<const lines_v2d *>(ximg + o));
         r23[j] = __builtin_nontemporal_load(reinterpret_cast<const lines_v2d *>(ximg + o + plane));
     }
+    __shared__ double s_t[LINES_WG][LN_ROWS + 1];
 #pragma unroll
     for (int j = 0; j < LN_G; ++j) {
-        const LnWhere &w = ws[j];
-        if (!(w.active && w.line_valid)) continue;
-        double *xl = x + ((int64_t)w.z * g.ny + w.y) * g.a;
-        if (w.w0 >= 0 && w.w0 + LN_CH <= g.a) {
-            lines_v2du a01, a23; a01.x = r01[j].x; a01.y = r01[j].y; a23.x = r23[j].x; a23.y = r23[j].y;
-            *reinterpret_cast<lines_v2du *>(xl + w.w0) = a01; *reinterpret_cast<lines_v2du *>(xl + w.w0 + 2) = a23;
-        } else {
-            const double v[LN_CH] = {r01[j].x, r01[j].y, r23[j].x, r23[j].y};
+        s_t[t][j * LN_CH] = r01[j].x; s_t[t][j * LN_CH + 1] = r01[j].y; s_t[t][j * LN_CH + 2] = r23[j].x; s_t[t][j * LN_CH + 3] = r23[j].y;
+    }
+    __syncthreads();
+    {
+        const int tile = ws[0].tile, S0 = ws[0].S;
 #pragma unroll
-            for (int u = 0; u < LN_CH; ++u) {
-                const int p = w.w0 + u;
-                if (p >= 0 && p < g.a) xl[p] = v[u];
-            }
+        for (int k = 0; k < LN_ROWS / 2; ++k) {
+            const LnPiece q = ln_piece(g, tile, S0, t + LINES_WG * k);
+            const int c = 2 * ((t + LINES_WG * k) % (LN_ROWS / 2));
+            // (a row inside its line always lies in a window that has run: every row of every line is some step's)
+            if (q.ok0 && q.ok1) { lines_v2du a; a.x = s_t[q.line][c]; a.y = s_t[q.line][c + 1]; *reinterpret_cast<lines_v2du *>(x + q.at) = a; }
+            else { if (q.ok0) x[q.at] = s_t[q.line][c]; if (q.ok1) x[q.at + 1] = s_t[q.line][c + 1]; }
         }
     }
 }
