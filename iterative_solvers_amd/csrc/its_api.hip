@@ -155,7 +155,7 @@ extern "C" int its_destroy(its_handle *h)
     for (auto &A : h->mat) free_csr(A);
     free_lines(h);
     dfree(h->D); dfree(h->b); dfree(h->r); dfree(h->tmp); dfree(h->x_a); dfree(h->x_b); dfree(h->x);
-    dfree(h->p); dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
+    dfree(h->p); dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev); dfree(h->gm_w2);
     dfree(h->pcg_w); dfree(h->pcg_s); dfree(h->pcg_z); dfree(h->pcg_pair[0]); dfree(h->pcg_pair[1]); dfree(h->gram_part); dfree(h->gram_h); dfree(h->mgs_slots);
     for (auto &e : h->prof_ev) (void)hipEventDestroy(e);
     for (auto &p : h->part) dfree(p);
@@ -273,6 +273,7 @@ static int build_sell(its_handle *h, CsrDev &A, int n, const int *rp)
 int its_upload_csr_local(its_handle *h, int which, int n_rows, int n_cols, int64_t nnz,
                          const int *row_ptr, const int *col, const double *val, int format)
 {
+    if (h) h->gm_ahead_iter = -1;
     if (!h || which < 0 || which > ITS_MAT_DU || n_rows < 0 || nnz < 0 || !row_ptr) return ITS_EINVAL;
     if (nnz > 0 && (!col || !val)) FAIL(h, ITS_EINVAL, "null col/val");
     if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) FAIL(h, ITS_EINVAL, "row_ptr[0] != 0 or row_ptr[n] != nnz");
@@ -647,6 +648,11 @@ extern "C" int its_set_option(its_handle *h, const char *name, int value)
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return ITS_OK;
     }
+    if (!strcmp(name, "gmres_ahead")) {
+        if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "gmres_ahead: 0 or 1");
+        h->gmres_ahead = value; h->gm_ahead_iter = -1;
+        return ITS_OK;
+    }
     if (!strcmp(name, "sweep_run")) {
         if (value != 0 && value != 1) FAIL(h, ITS_EINVAL, "sweep_run: 0 or 1");
         h->sweep_run = value;
@@ -800,6 +806,7 @@ static int finish_scalar(its_handle *h, double *part, double *out, int mode)
 
 extern "C" int its_upload_vectors(its_handle *h, const double *D, const double *b, const double *x0, int n)
 {
+    if (h) h->gm_ahead_iter = -1;
     if (!h || !D || !b || !x0) return ITS_EINVAL;
     if (!h->have[ITS_MAT_A] || n != h->n) FAIL(h, ITS_ESTATE, "upload the matrix first; n must equal its row count");
     HIPCHK(h, hipSetDevice(h->device));
@@ -823,6 +830,7 @@ extern "C" int its_upload_vectors(its_handle *h, const double *D, const double *
 
 extern "C" int its_init_residual(its_handle *h, double *r0_inf, double *r0_two)
 {
+    if (h) h->gm_ahead_iter = -1;
     debug_poison_lds(h);
     if (!h) return ITS_EINVAL;
     if (!h->x_a) FAIL(h, ITS_ESTATE, "its_upload_vectors first");
@@ -1215,6 +1223,7 @@ static int sweep(its_handle *h, double *x, const double *rhs, int first_level = 
 extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len, int precond_kind,
                                 int jacobi_mode, int gs_order)
 {
+    if (h) h->gm_ahead_iter = -1;
     if (!h) return ITS_EINVAL;
     if (solver_kind < ITS_JACOBI || solver_kind > ITS_GMRES) FAIL(h, ITS_EINVAL, "unknown solver kind");
     if (!h->residual_done) FAIL(h, ITS_ESTATE, "its_init_residual first (main.cpp:307 precedes :317)");
@@ -1289,8 +1298,11 @@ extern "C" int its_solver_setup(its_handle *h, int solver_kind, int restart_len,
         if (restart_len > (1 << 24)) FAIL(h, ITS_EINVAL, "restart_len beyond 2^24");
         const int m = h->m = restart_len;
         { int rcp = size_pinned(h, m); if (rcp) return rcp; }
-        dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev);
-        if (dalloc(h, &h->V, (((size_t)ne + 31) & ~(size_t)31) * (size_t)(m + 1)) || dalloc(h, &h->hcol_dev, m + 2) || dalloc(h, &h->y_dev, m + 1)) return ITS_EHIP;
+        dfree(h->V); dfree(h->hcol_dev); dfree(h->y_dev); dfree(h->gm_w2);
+        if (dalloc(h, &h->V, (((size_t)ne + 31) & ~(size_t)31) * (size_t)(m + 1)) || dalloc(h, &h->hcol_dev, m + 2) || dalloc(h, &h->y_dev, m + 1) ||
+            dalloc(h, &h->gm_w2, ne)) return ITS_EHIP;
+        HIPCHK(h, hipMemsetAsync(h->gm_w2, 0, (size_t)ne * sizeof(double), h->stream));
+        h->gm_ahead_iter = -1;
         h->Rm.assign((size_t)(m + 1) * m, 0.0); h->g.assign(m + 1, 0.0);
         h->cs.assign(m, 0.0); h->sn.assign(m, 0.0); h->hcol.assign(m + 2, 0.0);
         if (const char *e = getenv("ITS_GMRES_GIVENS")) h->gmres_givens = !strcmp(e, "dense") || !strcmp(e, "1");
@@ -1531,10 +1543,28 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     const int k = iter_count - h->restart_count * m;                  // gmres.hpp:113
     if (k < 0 || k >= m) FAIL(h, ITS_ESTATE, "GMRES inner index out of range: restart missing?");
     double *w = h->tmp;
-    SpmvArgs a; a.x = h->V + (size_t)k * ld; a.y = w;
-    int rc = solver_spmv(h, a, EPI_STORE);                            // gmres.hpp:234
-    if (rc) return rc;
-    if (h->precond == ITS_PRECOND_GS) { if ((rc = sweep(h, w, w))) return rc; }   // gmres.hpp:251
+    int rc;
+    if (h->gm_ahead_iter == iter_count && h->gm_ahead_restart == h->restart_count && h->gm_ahead_w) {
+        w = h->gm_ahead_w;                                            // queued behind the last trip's sweep (below): same kernels, same operands
+    } else {
+        SpmvArgs a; a.x = h->V + (size_t)k * ld; a.y = w;
+        if ((rc = solver_spmv(h, a, EPI_STORE))) return rc;           // gmres.hpp:234
+        if (h->precond == ITS_PRECOND_GS) { if ((rc = sweep(h, w, w))) return rc; }   // gmres.hpp:251
+    }
+    h->gm_ahead_iter = -1;
+    // the next trip's product, to be queued as soon as this trip's sweep is: v_{k+1} is the sweep's last write, nothing the
+    // host does with the Hessenberg column changes it.  Not at the end of a cycle (the restart rebuilds V), not across ranks
+    // (the halo exchange is a collective every rank would have to queue alike: kept out of a speculation)
+    auto queue_ahead = [&]() -> int {
+        if (!h->gmres_ahead || k + 1 >= m || its_dist_active(h) || !h->gm_w2) return ITS_OK;
+        double *wn = (w == h->tmp) ? h->gm_w2 : h->tmp;
+        SpmvArgs a2; a2.x = h->V + (size_t)(k + 1) * ld; a2.y = wn;
+        int rc2 = solver_spmv(h, a2, EPI_STORE);
+        if (rc2) return rc2;
+        if (h->precond == ITS_PRECOND_GS && (rc2 = sweep(h, wn, wn))) return rc2;
+        h->gm_ahead_w = wn; h->gm_ahead_iter = iter_count + 1; h->gm_ahead_restart = h->restart_count;
+        return ITS_OK;
+    };
     // the Hessenberg column is written straight into pinned host memory (region pin_h, m + 2 doubles), or copied
     // (the persistent Gram-Schmidt launch always writes the column to pinned memory — a launch that gave up is recognised
     // by the word it left armed; in read-back mode 2 the host then synchronizes before it reads, which is what that mode
@@ -1556,11 +1586,13 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
     if (persist) {
         HIPCHK(h, launch_mgs_persist(w, h->V, (int64_t)ld, k + 1, h->V + (size_t)(k + 1) * ld, hcol_out, h->mgs_slots, h->mgs_parity++, m, h->mgs_grid, n, h->stream,
                                      h->mgs_inject_fail > 0 ? (h->mgs_inject_fail--, h->mgs_inject_kind) : 0));
+        if ((rc = queue_ahead())) return rc;
         if ((rc = wait_pinned_word(h, hcol_out + (k + 1)))) return rc;
         if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + (k + 1)) == kPendingWord) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
             if (*reinterpret_cast<const volatile uint64_t *>(hcol_out + (k + 1)) == kPendingWord) {
                 persist = false;
+                h->gm_ahead_iter = -1;                                 // (what was queued read a v_{k+1} that was never written)
                 HIPCHK(h, mgs_persist_reset(h->mgs_slots, m, h->mgs_grid, h->stream));
                 if (h->watch_misses > 0) --h->watch_misses;            // the window that ran out was this launch's, not a slow trip's
                 if (++h->mgs_fallbacks >= 2) h->mgs_grid = 0;          // twice: this handle stays on the per-step kernels
@@ -1598,7 +1630,10 @@ static int trip_gmres(its_handle *h, int iter_count, double *res_host)
         if ((rc = allreduce_partials(h, next_part, 0))) return rc;
     }
     // H[k+1,k] = ||w||, V[k+1] = w / H[k+1,k]   (gmres.hpp:359,389)
-    if (!persist) launch_mgs_normalize(h->V + (size_t)(k + 1) * ld, w, prev_part, prev_scalar, hcol_out + (k + 1), n, h->stream);
+    if (!persist) {
+        launch_mgs_normalize(h->V + (size_t)(k + 1) * ld, w, prev_part, prev_scalar, hcol_out + (k + 1), n, h->stream);
+        if ((rc = queue_ahead())) return rc;
+    }
     HIPCHK(h, hipGetLastError());
     double *hc = h->hcol.data();
     if (hcol_pinned) {
@@ -1831,6 +1866,7 @@ extern "C" int its_iterate_n(its_handle *h, int iter_count0, int n_trips, double
 
 extern "C" int its_gmres_restart(its_handle *h, int iter_count)
 {
+    if (h) h->gm_ahead_iter = -1;
     debug_poison_lds(h);
     int rc = check_ready(h);
     if (rc) return rc;

@@ -45,6 +45,11 @@ struct its_handle {
     double *p = nullptr;
     // gmresArgs (gmres.hpp:16-42)
     double *V = nullptr, *hcol_dev = nullptr, *y_dev = nullptr;
+    // GMRES: the next trip's w = A v_{k+1} (+ preconditioner) queued behind this trip's Gram-Schmidt sweep, so that it runs
+    // while the host waits for the Hessenberg column and turns it (option "gmres_ahead", default 1).  gm_w2 alternates
+    // with tmp; gm_ahead_iter = the trip the product is for, -1 = none
+    double *gm_w2 = nullptr, *gm_ahead_w = nullptr;
+    int gm_ahead_iter = -1, gm_ahead_restart = -1, gmres_ahead = 1;
     int m = 0, restart_count = 0;
     double beta = 0.0;
     std::vector<double> Rm, g, cs, sn, hcol;   // host: R (col-major (m+1) x m), g, Givens c/s
